@@ -1,0 +1,171 @@
+/*
+ * mcx.h - batch (GPU) entry points of the MI355X build of libmontecarlo.
+ *
+ * The reference library answers "which driver serves this device" and "which
+ * loaded modules are roots / in use" one object at a time, by shelling out to
+ * kmod and walking sysfs:
+ *   - alias -> module resolution happens inside `modprobe`,
+ *       reference montecarlo/libmontecarlo.c:115-127 (mc_try_load_driver),
+ *       montecarlo/helper.c:76-82, and inside `modinfo -F alias`,
+ *       reference desktop/ui.py:1526-1531;
+ *   - holders / in-use / root filtering is one opendir per module,
+ *       reference montecarlo/libmontecarlo.c:446-473 (mc_module_has_holders),
+ *       montecarlo/libmontecarlo.c:573-725 (mc_driver_is_in_use),
+ *       desktop/ui.py:1565-1599 (root-module filter loop).
+ * A scalar per-string ABI cannot feed a GPU, so the same questions are
+ * exposed here over whole tables.  All entry points are plain C: pointers and
+ * sizes only.  Every function returns 0 on success or a negative MCX_E_* code;
+ * nothing is computed on the CPU as a fallback: without a usable HIP device
+ * mcx_ctx_create() fails with MCX_E_NO_DEVICE.
+ *
+ * Buffers named d_* are device pointers (hipMalloc memory or any pointer the
+ * HIP runtime accepts on the context's device); all others are host pointers.
+ * A context owns (or borrows) one HIP stream; *_dev entry points only enqueue
+ * work on it and return, host-buffer entry points synchronise before returning.
+ * A context is not thread safe: use one per thread.
+ */
+#ifndef MCX_H
+#define MCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcx_ctx mcx_ctx;
+
+enum {
+    MCX_OK = 0,
+    MCX_E_NO_DEVICE = -1,     /* no HIP device / HIP runtime error at create   */
+    MCX_E_BAD_ARG = -2,       /* NULL pointer, bad size, table not loaded ...  */
+    MCX_E_HIP = -3,           /* a HIP call failed; see mcx_last_error()       */
+    MCX_E_NOMEM = -4,
+    MCX_E_PATTERN = -5,       /* pattern outside the supported grammar         */
+    MCX_E_TOO_LARGE = -6,     /* size beyond a documented limit                */
+    MCX_E_NOT_LOADED = -7     /* alias table / dep graph not loaded yet        */
+};
+
+#define MCX_NO_MATCH 0xFFFFFFFFu
+
+/* flags for mcx_alias_table_load */
+#define MCX_TABLE_NORMALIZE_DASH 1u  /* map '-' to '_' outside [...] in patterns
+                                        and in queried strings, as kmod does
+                                        before it calls fnmatch               */
+
+/* in_flags bits (per module) for the dependency kernels */
+#define MCX_F_LOADED 1u
+#define MCX_F_BOUND  2u
+#define MCX_F_SAFE   4u
+/* out_flags bits (per module) */
+#define MCX_O_HAS_HOLDERS 1u
+#define MCX_O_IN_USE      2u
+#define MCX_O_ROOT        4u
+
+/* direction for mcx_dep_closure */
+#define MCX_CLOSURE_HOLDERS 0  /* everything that (transitively) needs a seed  */
+#define MCX_CLOSURE_DEPS    1  /* everything a seed (transitively) needs       */
+
+/* ---- context ------------------------------------------------------------ */
+
+/* stream: a hipStream_t to borrow (e.g. the caller's current stream), or NULL
+ * to let the context create and own one. */
+int  mcx_ctx_create(int device_ordinal, void *stream, mcx_ctx **out);
+void mcx_ctx_destroy(mcx_ctx *ctx);
+int  mcx_sync(mcx_ctx *ctx);
+void *mcx_ctx_stream(mcx_ctx *ctx);
+const char *mcx_strerror(int rc);
+/* text of the last failure on this context (HIP error string, offending
+ * pattern index ...); never NULL. */
+const char *mcx_last_error(mcx_ctx *ctx);
+
+/* device memory helpers for callers that have no HIP binding of their own */
+int mcx_dev_alloc(mcx_ctx *ctx, size_t bytes, void **d_out);
+int mcx_dev_free(mcx_ctx *ctx, void *d_ptr);
+int mcx_h2d(mcx_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int mcx_d2h(mcx_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+/* stream-ordered timing: begin/end bracket work enqueued on the context's
+ * stream with HIP events; end returns the elapsed milliseconds. */
+int mcx_timer_begin(mcx_ctx *ctx);
+int mcx_timer_end(mcx_ctx *ctx, float *ms_out);
+
+/* ---- K1: modalias x alias-pattern glob match ---------------------------- */
+
+/*
+ * Load a modules.alias-style table: P patterns packed in `arena`, pattern j is
+ * arena[a_off[j] .. a_off[j+1]) (no terminator needed, no NUL inside), owned
+ * by module id a_mod[j].  Table order is file order.  Replaces the alias
+ * lookup kmod performs for the reference at montecarlo/libmontecarlo.c:123.
+ * Semantics of a pattern are those of glibc fnmatch(pattern, string, 0) in
+ * the C locale.  Supported grammar: literals, '?', '*', '\' escapes and
+ * bracket expressions with literals, ranges, leading '!' or '^' and leading
+ * ']'.  POSIX [:class:], [=x=] and [.x.] sub-expressions are rejected with
+ * MCX_E_PATTERN (no modules.alias line uses them).
+ */
+int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
+                         const uint32_t *a_mod, uint32_t P, uint32_t flags);
+
+/*
+ * Match N strings (string i = S[s_off[i] .. s_off[i+1])) against the loaded
+ * table.  first_idx[i] = smallest j with fnmatch(pattern_j, string_i, 0) == 0,
+ * or MCX_NO_MATCH; count[i] = number of matching patterns.  Host buffers.
+ */
+int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N,
+                    uint32_t *first_idx, uint32_t *count);
+/* Same with everything resident on the device; enqueues and returns. */
+int mcx_alias_match_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N,
+                        void *d_first_idx, void *d_count);
+/* driver_mod[i] = a_mod[first_idx[i]] (MCX_NO_MATCH if none); device buffers. */
+int mcx_alias_driver_mod_dev(mcx_ctx *ctx, const void *d_first_idx, uint32_t N,
+                             void *d_driver_mod);
+/* hw_alias[m] = 1 iff module m owns a pattern whose text starts with one of
+ * pci: usb: platform: hid: serio: of:  (reference desktop/ui.py:1540-1549);
+ * n_modules bytes are written to the host buffer. */
+int mcx_alias_hw_flags(mcx_ctx *ctx, uint32_t n_modules, uint8_t *hw_alias);
+/* number of patterns / bytes of device memory held by the table */
+int mcx_alias_table_info(mcx_ctx *ctx, uint32_t *P_out, uint64_t *device_bytes_out);
+
+/* ---- K2: module dependency graph ---------------------------------------- */
+
+/*
+ * Load the direct-dependency graph in CSR form: edge u -> col[k] for
+ * k in [rowptr[u], rowptr[u+1]) means "u needs col[k]" (col[k] is held by u,
+ * the relation sysfs shows as /sys/module/<col[k]>/holders/<u>, read by the
+ * reference at montecarlo/libmontecarlo.c:446-473).
+ */
+int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col,
+                       uint32_t V, uint32_t E);
+/*
+ * out_flags[v]:  HAS_HOLDERS = LOADED[v] and some LOADED u has edge u -> v
+ *                IN_USE      = LOADED[v] and (BOUND[v] or HAS_HOLDERS[v])
+ *                              (montecarlo/libmontecarlo.c:573-725)
+ *                ROOT        = LOADED[v] and SAFE[v] and not HAS_HOLDERS[v]
+ *                              (desktop/ui.py:1565-1577)
+ * refcnt (optional, may be NULL): number of LOADED holders of v plus 1 if
+ * BOUND[v]; 0xFFFFFFFF for modules that are not loaded, the batch analogue of
+ * the -1 of mc_get_module_refcount (montecarlo/libmontecarlo.c:476-495).
+ */
+int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags,
+                  uint32_t *refcnt);
+int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags,
+                      void *d_refcnt);
+/*
+ * Reachability restricted to LOADED modules.  Bitmaps are ceil(V/32) words,
+ * bit v = word v/32, bit v%32.  direction MCX_CLOSURE_HOLDERS: out = seeds'
+ * transitive holders (what must be unloaded before the seeds, the situation
+ * the reference reports at desktop/ui.py:1679-1680); MCX_CLOSURE_DEPS: out =
+ * everything the seeds transitively need.  Seeds that are LOADED are part of
+ * the result.  edges_scanned / levels are optional outputs.
+ */
+int mcx_dep_closure(mcx_ctx *ctx, const uint8_t *in_flags, const uint32_t *seed_bitmap,
+                    uint32_t *out_bitmap, int direction,
+                    uint64_t *edges_scanned, uint32_t *levels);
+int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed_bitmap,
+                        void *d_out_bitmap, int direction,
+                        uint64_t *edges_scanned, uint32_t *levels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCX_H */

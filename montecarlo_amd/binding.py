@@ -1,0 +1,288 @@
+"""ctypes binding of the mcx_* C ABI (include/mcx.h).
+
+Mirrors the way the reference loads its library: ``ctypes.CDLL(LIB_PATH)`` with
+explicit argtypes/restype and caller-allocated buffers (reference
+desktop/ui.py:53-103).  The environment variable ``MONTECARLO_LIB`` overrides
+the library path, like the reference's ``MONTECARLO_DEV`` switch
+(desktop/ui.py:44-51).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+NO_MATCH = 0xFFFFFFFF
+F_LOADED, F_BOUND, F_SAFE = 1, 2, 4
+O_HAS_HOLDERS, O_IN_USE, O_ROOT = 1, 2, 4
+CLOSURE_HOLDERS, CLOSURE_DEPS = 0, 1
+TABLE_NORMALIZE_DASH = 1
+
+_c_u32p = ctypes.POINTER(ctypes.c_uint32)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_vp = ctypes.c_void_p
+
+_LIB = None
+
+
+class McxError(RuntimeError):
+    def __init__(self, rc, what, detail=""):
+        self.rc = rc
+        super().__init__(f"{what}: rc={rc} ({detail})" if detail else f"{what}: rc={rc}")
+
+
+def library_path():
+    env = os.environ.get("MONTECARLO_LIB")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmontecarlo.so")
+
+
+def load_library():
+    """Load libmontecarlo.so; raises OSError when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise OSError(
+            f"{path} not found: build it with `make -C montecarlo_amd/csrc` "
+            "(there is no CPU fallback for the batch path)"
+        )
+    lib = ctypes.CDLL(path)
+    sig = {
+        "mcx_ctx_create": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
+        "mcx_ctx_destroy": (None, [_vp]),
+        "mcx_sync": (ctypes.c_int, [_vp]),
+        "mcx_ctx_stream": (_vp, [_vp]),
+        "mcx_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+        "mcx_last_error": (ctypes.c_char_p, [_vp]),
+        "mcx_dev_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+        "mcx_dev_free": (ctypes.c_int, [_vp, _vp]),
+        "mcx_h2d": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+        "mcx_d2h": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+        "mcx_timer_begin": (ctypes.c_int, [_vp]),
+        "mcx_timer_end": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+        "mcx_alias_table_load": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32]),
+        "mcx_alias_match": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, _vp, _vp]),
+        "mcx_alias_match_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, _vp, _vp]),
+        "mcx_alias_driver_mod_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
+        "mcx_alias_hw_flags": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
+        "mcx_alias_table_info": (
+            ctypes.c_int,
+            [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_dep_graph_load": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32]),
+        "mcx_dep_flags": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+        "mcx_dep_flags_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+        "mcx_dep_closure": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)],
+        ),
+        "mcx_dep_closure_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)],
+        ),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None else None
+
+
+def _as(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def pack_strings(strings):
+    """list of bytes -> (arena uint8[nbytes], offsets uint32[n+1])"""
+    off = np.zeros(len(strings) + 1, dtype=np.uint32)
+    if strings:
+        off[1:] = np.cumsum([len(s) for s in strings], dtype=np.uint64).astype(np.uint32)
+    arena = np.frombuffer(b"".join(strings), dtype=np.uint8).copy() if strings else np.zeros(0, np.uint8)
+    return arena, off
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = _vp()
+        ctx._check(ctx.lib.mcx_dev_alloc(ctx.h, self.nbytes, ctypes.byref(p)), "mcx_dev_alloc")
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.mcx_h2d(self.ctx.h, self.ptr, _ptr(arr), arr.nbytes), "mcx_h2d")
+        return self
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.mcx_d2h(self.ctx.h, _ptr(out), self.ptr, out.nbytes), "mcx_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.mcx_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One GPU context (one HIP stream).  Not thread safe: one per thread."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.mcx_ctx_create(int(device), stream, ctypes.byref(h))
+        if rc != 0:
+            raise McxError(rc, "mcx_ctx_create", self.lib.mcx_strerror(rc).decode())
+        self.h = h.value
+        self.P = 0
+        self.V = 0
+        self.E = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mcx_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            detail = self.lib.mcx_last_error(self.h).decode(errors="replace")
+            raise McxError(rc, what, detail or self.lib.mcx_strerror(rc).decode())
+
+    def sync(self):
+        self._check(self.lib.mcx_sync(self.h), "mcx_sync")
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 1)).upload(arr)
+
+    def timer_begin(self):
+        self._check(self.lib.mcx_timer_begin(self.h), "mcx_timer_begin")
+
+    def timer_end(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.mcx_timer_end(self.h, ctypes.byref(ms)), "mcx_timer_end")
+        return ms.value
+
+    # ---- K1 ----------------------------------------------------------------
+    def alias_table_load(self, arena, a_off, a_mod, flags=0):
+        arena = _as(arena, np.uint8)
+        a_off = _as(a_off, np.uint32)
+        a_mod = _as(a_mod, np.uint32)
+        P = len(a_off) - 1
+        if len(a_mod) != P:
+            raise ValueError("a_mod must have one entry per pattern")
+        self._check(
+            self.lib.mcx_alias_table_load(self.h, _ptr(arena), _ptr(a_off), _ptr(a_mod), P, flags),
+            "mcx_alias_table_load",
+        )
+        self.P = P
+
+    def alias_match(self, S, s_off):
+        S = _as(S, np.uint8)
+        s_off = _as(s_off, np.uint32)
+        N = len(s_off) - 1
+        first = np.empty(N, dtype=np.uint32)
+        count = np.empty(N, dtype=np.uint32)
+        self._check(
+            self.lib.mcx_alias_match(self.h, _ptr(S), _ptr(s_off), N, _ptr(first), _ptr(count)),
+            "mcx_alias_match",
+        )
+        return first, count
+
+    def alias_match_dev(self, d_S, d_s_off, N, d_first, d_count):
+        self._check(
+            self.lib.mcx_alias_match_dev(self.h, d_S, d_s_off, N, d_first, d_count), "mcx_alias_match_dev"
+        )
+
+    def alias_driver_mod_dev(self, d_first, N, d_out):
+        self._check(self.lib.mcx_alias_driver_mod_dev(self.h, d_first, N, d_out), "mcx_alias_driver_mod_dev")
+
+    def alias_hw_flags(self, n_modules):
+        out = np.zeros(n_modules, dtype=np.uint8)
+        self._check(self.lib.mcx_alias_hw_flags(self.h, n_modules, _ptr(out)), "mcx_alias_hw_flags")
+        return out
+
+    def alias_table_info(self):
+        P = ctypes.c_uint32()
+        b = ctypes.c_uint64()
+        self._check(self.lib.mcx_alias_table_info(self.h, ctypes.byref(P), ctypes.byref(b)), "mcx_alias_table_info")
+        return P.value, b.value
+
+    # ---- K2 ----------------------------------------------------------------
+    def dep_graph_load(self, rowptr, col):
+        rowptr = _as(rowptr, np.uint32)
+        col = _as(col, np.uint32)
+        V = len(rowptr) - 1
+        E = len(col)
+        self._check(self.lib.mcx_dep_graph_load(self.h, _ptr(rowptr), _ptr(col), V, E), "mcx_dep_graph_load")
+        self.V, self.E = V, E
+
+    def dep_flags(self, in_flags, want_refcnt=True):
+        in_flags = _as(in_flags, np.uint8)
+        if len(in_flags) != self.V:
+            raise ValueError("in_flags must have V entries")
+        out = np.empty(self.V, dtype=np.uint8)
+        ref = np.empty(self.V, dtype=np.uint32) if want_refcnt else None
+        self._check(self.lib.mcx_dep_flags(self.h, _ptr(in_flags), _ptr(out), _ptr(ref)), "mcx_dep_flags")
+        return out, ref
+
+    def dep_flags_dev(self, d_in, d_out, d_ref=None):
+        self._check(self.lib.mcx_dep_flags_dev(self.h, d_in, d_out, d_ref), "mcx_dep_flags_dev")
+
+    def dep_closure(self, in_flags, seed_bitmap, direction=CLOSURE_HOLDERS):
+        in_flags = _as(in_flags, np.uint8)
+        seed_bitmap = _as(seed_bitmap, np.uint32)
+        W = (self.V + 31) // 32
+        if len(in_flags) != self.V or len(seed_bitmap) != W:
+            raise ValueError("in_flags needs V entries and seed_bitmap ceil(V/32) words")
+        out = np.zeros(W, dtype=np.uint32)
+        edges = ctypes.c_uint64()
+        levels = ctypes.c_uint32()
+        self._check(
+            self.lib.mcx_dep_closure(
+                self.h, _ptr(in_flags), _ptr(seed_bitmap), _ptr(out), direction, ctypes.byref(edges),
+                ctypes.byref(levels)
+            ),
+            "mcx_dep_closure",
+        )
+        return out, edges.value, levels.value
+
+    def dep_closure_dev(self, d_in, d_seed, d_out, direction=CLOSURE_HOLDERS, want_stats=True):
+        edges = ctypes.c_uint64()
+        levels = ctypes.c_uint32()
+        self._check(
+            self.lib.mcx_dep_closure_dev(
+                self.h, d_in, d_seed, d_out, direction,
+                ctypes.byref(edges) if want_stats else None,
+                ctypes.byref(levels) if want_stats else None,
+            ),
+            "mcx_dep_closure_dev",
+        )
+        return edges.value, levels.value

@@ -1,0 +1,109 @@
+"""Synthetic inputs (binding of lib/libmcxsynth.so, csrc/mcx_synth.c).
+
+Every item is a pure function of (seed, kind, index), so ranks can generate
+their own shards.  Arrays are numpy: arenas are uint8, offsets uint32.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_vp = ctypes.c_void_p
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmcxsynth.so")
+        if not os.path.exists(path):
+            raise OSError(f"{path} not found: build it with `make -C montecarlo_amd/csrc`")
+        lib = ctypes.CDLL(path)
+        u64, u32 = ctypes.c_uint64, ctypes.c_uint32
+        lib.mcxs_alias_table.restype = u64
+        lib.mcxs_alias_table.argtypes = [u64, u32, u32, _vp, u64, _vp, _vp]
+        lib.mcxs_alias_modules.restype = u32
+        lib.mcxs_alias_modules.argtypes = [u32]
+        lib.mcxs_modalias_strings.restype = u64
+        lib.mcxs_modalias_strings.argtypes = [u64, u32, u64, u64, _vp, u64, _vp]
+        lib.mcxs_dep_graph.restype = u64
+        lib.mcxs_dep_graph.argtypes = [u64, u32, u32, _vp, _vp, u64]
+        lib.mcxs_dep_flags.restype = None
+        lib.mcxs_dep_flags.argtypes = [u64, _vp, _vp, u32, u32, _vp]
+        lib.mcxs_seed_bitmap.restype = u32
+        lib.mcxs_seed_bitmap.argtypes = [u64, u32, u32, _vp, _vp]
+        lib.mcxs_module_names.restype = u64
+        lib.mcxs_module_names.argtypes = [u64, u32, u32, _vp, u64, _vp]
+        _LIB = lib
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def alias_table(seed, P, j0=0, j1=None):
+    """patterns j0..j1 of a P-pattern table -> (arena, a_off, a_mod)"""
+    j1 = P if j1 is None else j1
+    lib = _lib()
+    n = j1 - j0
+    a_off = np.zeros(n + 1, dtype=np.uint32)
+    a_mod = np.zeros(n, dtype=np.uint32)
+    nbytes = lib.mcxs_alias_table(seed, j0, j1, None, 0, None, None)
+    arena = np.zeros(max(nbytes, 1), dtype=np.uint8)
+    lib.mcxs_alias_table(seed, j0, j1, _p(arena), nbytes, _p(a_off), _p(a_mod))
+    return arena[:nbytes], a_off, a_mod
+
+
+def alias_modules(P):
+    return _lib().mcxs_alias_modules(P)
+
+
+def modalias_strings(seed, P, N, i0=0, i1=None):
+    """strings i0..i1 of an N-string batch drawn against a P-pattern table"""
+    i1 = N if i1 is None else i1
+    lib = _lib()
+    n = i1 - i0
+    s_off = np.zeros(n + 1, dtype=np.uint32)
+    nbytes = lib.mcxs_modalias_strings(seed, P, i0, i1, None, 0, None)
+    if nbytes >= 2**32:
+        raise ValueError("string arena beyond 4 GiB: generate in shards")
+    S = np.zeros(max(nbytes, 1), dtype=np.uint8)
+    lib.mcxs_modalias_strings(seed, P, i0, i1, _p(S), nbytes, _p(s_off))
+    return S[:nbytes], s_off
+
+
+def dep_graph(seed, V, mean_deg=10):
+    lib = _lib()
+    rowptr = np.zeros(V + 1, dtype=np.uint32)
+    E = lib.mcxs_dep_graph(seed, V, mean_deg, None, None, 0)
+    col = np.zeros(max(E, 1), dtype=np.uint32)
+    lib.mcxs_dep_graph(seed, V, mean_deg, _p(rowptr), _p(col), E)
+    return rowptr, col[:E]
+
+
+def dep_flags(seed, rowptr, col, load_pm=50):
+    V = len(rowptr) - 1
+    f = np.zeros(max(V, 1), dtype=np.uint8)
+    colc = np.ascontiguousarray(col if len(col) else np.zeros(1, np.uint32), dtype=np.uint32)
+    _lib().mcxs_dep_flags(seed, _p(np.ascontiguousarray(rowptr, dtype=np.uint32)), _p(colc), V, load_pm, _p(f))
+    return f[:V]
+
+
+def seed_bitmap(seed, in_flags, n_seeds):
+    V = len(in_flags)
+    bm = np.zeros(max((V + 31) // 32, 1), dtype=np.uint32)
+    f = np.ascontiguousarray(in_flags if V else np.zeros(1, np.uint8), dtype=np.uint8)
+    got = _lib().mcxs_seed_bitmap(seed, V, n_seeds, _p(f), _p(bm))
+    return bm[: (V + 31) // 32], got
+
+
+def module_names(seed, V, m0=0, m1=None):
+    m1 = V if m1 is None else m1
+    lib = _lib()
+    off = np.zeros(m1 - m0 + 1, dtype=np.uint32)
+    nbytes = lib.mcxs_module_names(seed, m0, m1, None, 0, None)
+    buf = np.zeros(max(nbytes, 1), dtype=np.uint8)
+    lib.mcxs_module_names(seed, m0, m1, _p(buf), nbytes, _p(off))
+    raw = buf[:nbytes].tobytes()
+    return [raw[off[k]:off[k + 1]].decode() for k in range(m1 - m0)]

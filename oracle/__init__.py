@@ -1,0 +1,113 @@
+"""CPU oracle and CPU twin - TEST INFRASTRUCTURE ONLY.
+
+Loaded by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as
+the checker.  Nothing in montecarlo_amd/ imports this package.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_vp = ctypes.c_void_p
+_ORC = None
+_TWIN = None
+NO_MATCH = 0xFFFFFFFF
+
+
+def build():
+    """Compile the oracle libraries (plain gcc/g++, seconds)."""
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def _load(name):
+    path = os.path.join(_HERE, "_build", name)
+    if not os.path.exists(path):
+        build()
+    return ctypes.CDLL(path)
+
+
+def oracle():
+    global _ORC
+    if _ORC is None:
+        lib = _load("libmcx_oracle.so")
+        u32, u64 = ctypes.c_uint32, ctypes.c_uint64
+        lib.orc_fnmatch.restype = ctypes.c_int
+        lib.orc_fnmatch.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        lib.orc_alias_match.restype = u64
+        lib.orc_alias_match.argtypes = [_vp, _vp, u32, _vp, _vp, u32, u32, ctypes.c_int, _vp, _vp]
+        lib.orc_dep_flags.restype = None
+        lib.orc_dep_flags.argtypes = [_vp, _vp, u32, _vp, _vp, _vp]
+        lib.orc_dep_closure.restype = u64
+        lib.orc_dep_closure.argtypes = [_vp, _vp, u32, u32, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(u32)]
+        lib.orc_safe_name.restype = ctypes.c_int
+        lib.orc_safe_name.argtypes = [ctypes.c_char_p]
+        lib.orc_has_hw_alias.restype = ctypes.c_int
+        lib.orc_has_hw_alias.argtypes = [ctypes.c_char_p]
+        _ORC = lib
+    return _ORC
+
+
+def twin():
+    global _TWIN
+    if _TWIN is None:
+        lib = _load("libmcx_twin.so")
+        u32 = ctypes.c_uint32
+        lib.twin_compile_check.restype = ctypes.c_int
+        lib.twin_compile_check.argtypes = [ctypes.c_char_p, u32, ctypes.c_int]
+        lib.twin_fnmatch.restype = ctypes.c_int
+        lib.twin_fnmatch.argtypes = [ctypes.c_char_p, u32, ctypes.c_char_p, u32]
+        lib.twin_alias_match.restype = ctypes.c_int
+        lib.twin_alias_match.argtypes = [_vp, _vp, u32, _vp, _vp, u32, u32, ctypes.c_int, _vp, _vp]
+        _TWIN = lib
+    return _TWIN
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _c(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a if a.size else np.zeros(1, dtype=dt)
+
+
+def alias_match(arena, a_off, S, s_off, normalize_dash=False, i0=0, i1=None, use_twin=False):
+    """(first_idx, count) for strings i0..i1 by glibc fnmatch (or the CPU twin)."""
+    a_off = np.ascontiguousarray(a_off, dtype=np.uint32)
+    s_off = np.ascontiguousarray(s_off, dtype=np.uint32)
+    P, N = len(a_off) - 1, len(s_off) - 1
+    i1 = N if i1 is None else i1
+    first = np.full(N, NO_MATCH, dtype=np.uint32)
+    count = np.zeros(N, dtype=np.uint32)
+    A, SS = _c(arena, np.uint8), _c(S, np.uint8)
+    if use_twin:
+        rc = twin().twin_alias_match(_p(A), _p(a_off), P, _p(SS), _p(s_off), i0, i1, int(normalize_dash),
+                                     _p(first), _p(count))
+        if rc != 0:
+            raise RuntimeError(f"twin_alias_match rc={rc}")
+    else:
+        oracle().orc_alias_match(_p(A), _p(a_off), P, _p(SS), _p(s_off), i0, i1, int(normalize_dash),
+                                 _p(first), _p(count))
+    return first[i0:i1], count[i0:i1]
+
+
+def dep_flags(rowptr, col, in_flags):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
+    V = len(rowptr) - 1
+    out = np.zeros(max(V, 1), dtype=np.uint8)
+    ref = np.zeros(max(V, 1), dtype=np.uint32)
+    oracle().orc_dep_flags(_p(rowptr), _p(_c(col, np.uint32)), V, _p(_c(in_flags, np.uint8)), _p(out), _p(ref))
+    return out[:V], ref[:V]
+
+
+def dep_closure(rowptr, col, in_flags, seed_bitmap, direction=0):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
+    V, E = len(rowptr) - 1, len(col)
+    W = (V + 31) // 32
+    out = np.zeros(max(W, 1), dtype=np.uint32)
+    lv = ctypes.c_uint32()
+    scanned = oracle().orc_dep_closure(_p(rowptr), _p(_c(col, np.uint32)), V, E, _p(_c(in_flags, np.uint8)),
+                                       _p(_c(seed_bitmap, np.uint32)), _p(out), direction, ctypes.byref(lv))
+    return out[:W], scanned, lv.value

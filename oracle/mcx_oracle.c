@@ -1,0 +1,365 @@
+/*
+ * mcx_oracle.c - CPU oracle for the batch hot path.  TEST INFRASTRUCTURE ONLY:
+ * nothing under oracle/ is linked, imported or called by the product library;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * as the checker.
+ *
+ * PARITY STATUS: "parity unpinned" by the reference.  The reference holds no
+ * tests, fixtures or golden vectors for this path, and it computes neither the
+ * alias match nor the dependency closure itself: it shells out to kmod
+ * (`modprobe`, reference montecarlo/libmontecarlo.c:123,133 and
+ * montecarlo/helper.c:76-82; `modinfo -F alias`, reference
+ * desktop/ui.py:1526-1531).  kmod is a third-party dependency absent from the
+ * reference tree (Debian/Ubuntu package kmod 29 in this image); it decides an
+ * alias match with glibc fnmatch(alias_pattern, modalias, 0) after mapping '-'
+ * to '_' outside brackets.  The oracle therefore
+ *   - K1: calls glibc's own fnmatch(3) (flags 0, C locale forced), i.e. the
+ *     function kmod executes, not a re-derivation of it; tests/golden holds
+ *     outputs of kmod 29's `modprobe -R` produced in this image for a spot
+ *     check of table order and multi-match behaviour;
+ *   - K2: restates what the reference reads from sysfs one module at a time,
+ *     mc_module_has_holders (reference montecarlo/libmontecarlo.c:446-473),
+ *     mc_driver_is_in_use (573-725), mc_get_module_refcount (476-495) and the
+ *     root-module loop (reference desktop/ui.py:1565-1599), over a CSR graph,
+ *     plus a queue BFS for the closure;
+ *   - safe-module name filter: restates the tables of is_safe_module
+ *     (reference desktop/ui.py:1391-1518) literally.
+ */
+#define _GNU_SOURCE
+#include <fnmatch.h>
+#include <locale.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_NO_MATCH 0xFFFFFFFFu
+
+/* ---- K1 ------------------------------------------------------------------ */
+
+typedef struct {
+    locale_t c_loc, old;
+} orc_locale_t;
+
+static void orc_enter_c_locale(orc_locale_t *l)
+{
+    l->c_loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    l->old = l->c_loc ? uselocale(l->c_loc) : (locale_t)0;
+}
+
+static void orc_leave_c_locale(orc_locale_t *l)
+{
+    if (l->c_loc) {
+        uselocale(l->old);
+        freelocale(l->c_loc);
+    }
+}
+
+/* One pair, for differential tests: fnmatch(pattern, string, 0) in the C
+ * locale; 1 = match, 0 = no match. */
+int orc_fnmatch(const char *pattern, const char *string)
+{
+    orc_locale_t l;
+    orc_enter_c_locale(&l);
+    int r = fnmatch(pattern, string, 0) == 0;
+    orc_leave_c_locale(&l);
+    return r;
+}
+
+/*
+ * strings i in [i0, i1) of the batch against all P patterns.
+ * first_idx[i] = smallest matching pattern index or ORC_NO_MATCH, count[i] =
+ * number of matching patterns.  normalize_dash reproduces kmod's alias
+ * normalisation on both sides ('-' -> '_' outside [...]).
+ * Returns the number of fnmatch calls made.
+ */
+/* kmod's rule (libkmod-util.c, alias_normalize / underscores): '-' becomes
+ * '_' outside [...]; an unmatched bracket is an error, and kmod then drops
+ * the alias line or refuses the query.  Returns 0 on such an error. */
+static int orc_normalize(char *s)
+{
+    for (size_t i = 0; s[i]; ++i) {
+        if (s[i] == '-') {
+            s[i] = '_';
+        } else if (s[i] == ']') {
+            return 0;
+        } else if (s[i] == '[') {
+            while (s[i] && s[i] != ']')
+                ++i;
+            if (!s[i])
+                return 0;
+        }
+    }
+    return 1;
+}
+
+uint64_t orc_alias_match(const char *arena, const uint32_t *a_off, uint32_t P,
+                         const char *S, const uint32_t *s_off, uint32_t i0, uint32_t i1,
+                         int normalize_dash, uint32_t *first_idx, uint32_t *count)
+{
+    /* NUL-terminated copies: fnmatch takes C strings */
+    size_t abytes = a_off[P] + (size_t)P + 1;
+    char *pat = (char *)malloc(abytes);
+    size_t *pstart = (size_t *)malloc(sizeof(size_t) * ((size_t)P + 1));
+    size_t w = 0;
+    for (uint32_t j = 0; j < P; ++j) {
+        size_t n = a_off[j + 1] - a_off[j];
+        pstart[j] = w;
+        memcpy(pat + w, arena + a_off[j], n);
+        pat[w + n] = 0;
+        if (normalize_dash && !orc_normalize(pat + w))
+            pstart[j] = (size_t)-1; /* kmod ignores such a line */
+        w += n + 1;
+    }
+    size_t maxlen = 0;
+    for (uint32_t i = i0; i < i1; ++i)
+        if (s_off[i + 1] - s_off[i] > maxlen)
+            maxlen = s_off[i + 1] - s_off[i];
+    char *str = (char *)malloc(maxlen + 1);
+    orc_locale_t l;
+    orc_enter_c_locale(&l);
+    uint64_t calls = 0;
+    for (uint32_t i = i0; i < i1; ++i) {
+        size_t n = s_off[i + 1] - s_off[i];
+        memcpy(str, S + s_off[i], n);
+        str[n] = 0;
+        int ok = 1;
+        if (normalize_dash)
+            ok = orc_normalize(str);
+        uint32_t first = ORC_NO_MATCH, cnt = 0;
+        for (uint32_t j = 0; ok && j < P; ++j) {
+            if (pstart[j] == (size_t)-1)
+                continue;
+            if (fnmatch(pat + pstart[j], str, 0) == 0) {
+                if (first == ORC_NO_MATCH)
+                    first = j;
+                ++cnt;
+            }
+        }
+        calls += P;
+        first_idx[i] = first;
+        count[i] = cnt;
+    }
+    orc_leave_c_locale(&l);
+    free(str);
+    free(pstart);
+    free(pat);
+    return calls;
+}
+
+/* ---- K2 ------------------------------------------------------------------ */
+
+#define F_LOADED 1u
+#define F_BOUND 2u
+#define F_SAFE 4u
+#define O_HAS_HOLDERS 1u
+#define O_IN_USE 2u
+#define O_ROOT 4u
+
+/*
+ * rowptr/col: u -> col[k] means "u needs col[k]" (col[k] has holder u).
+ * HAS_HOLDERS follows mc_module_has_holders: /sys/module/<v>/holders lists the
+ * loaded modules that use v (reference libmontecarlo.c:446-473); IN_USE
+ * follows mc_driver_is_in_use: a bound device, else holders (573-725); ROOT is
+ * the survivor of the dashboard loop: loaded, passes is_safe_module and is not
+ * a used driver (folded into SAFE), has no holders (ui.py:1565-1577).
+ * refcnt mirrors /sys/module/<v>/refcnt read by mc_get_module_refcount
+ * (476-495): holders + bound devices, -1 (0xFFFFFFFF) when absent.
+ */
+void orc_dep_flags(const uint32_t *rowptr, const uint32_t *col, uint32_t V,
+                   const uint8_t *in_flags, uint8_t *out_flags, uint32_t *refcnt)
+{
+    uint32_t *holders = (uint32_t *)calloc(V ? V : 1, sizeof(uint32_t));
+    for (uint32_t u = 0; u < V; ++u) {
+        if (!(in_flags[u] & F_LOADED))
+            continue;
+        for (uint32_t k = rowptr[u]; k < rowptr[u + 1]; ++k) {
+            uint32_t v = col[k];
+            if (in_flags[v] & F_LOADED)
+                holders[v]++;
+        }
+    }
+    for (uint32_t v = 0; v < V; ++v) {
+        uint8_t f = in_flags[v], o = 0;
+        if (f & F_LOADED) {
+            if (holders[v])
+                o |= O_HAS_HOLDERS;
+            if ((f & F_BOUND) || holders[v])
+                o |= O_IN_USE;
+            if ((f & F_SAFE) && !holders[v])
+                o |= O_ROOT;
+        }
+        out_flags[v] = o;
+        if (refcnt)
+            refcnt[v] = (f & F_LOADED) ? holders[v] + ((f & F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
+    }
+    free(holders);
+}
+
+/*
+ * direction 0: out = loaded modules from which a loaded seed is reachable
+ * along "needs" edges through loaded modules only (the modules that must go
+ * before the seeds can be unloaded, the condition the reference reports at
+ * desktop/ui.py:1679-1680); direction 1: out = loaded modules reachable from
+ * a loaded seed.  Bitmaps: bit v = word v/32, bit v%32.
+ * Returns edges scanned; *levels = BFS depth (number of frontier expansions
+ * that found at least one vertex to expand).
+ */
+uint64_t orc_dep_closure(const uint32_t *rowptr, const uint32_t *col, uint32_t V, uint32_t E,
+                         const uint8_t *in_flags, const uint32_t *seed, uint32_t *out,
+                         int direction, uint32_t *levels)
+{
+    const uint32_t *rp = rowptr, *cl = col;
+    uint32_t *rrow = NULL, *rcol = NULL;
+    if (direction == 0) {
+        /* reverse CSR by counting sort */
+        rrow = (uint32_t *)calloc((size_t)V + 2, sizeof(uint32_t));
+        rcol = (uint32_t *)malloc(sizeof(uint32_t) * (E ? E : 1));
+        for (uint32_t k = 0; k < E; ++k)
+            rrow[col[k] + 2]++;
+        for (uint32_t v = 0; v < V; ++v)
+            rrow[v + 2] += rrow[v + 1];
+        for (uint32_t u = 0; u < V; ++u)
+            for (uint32_t k = rowptr[u]; k < rowptr[u + 1]; ++k)
+                rcol[rrow[col[k] + 1]++] = u;
+        rp = rrow;
+        cl = rcol;
+    }
+    uint32_t W = (V + 31) / 32;
+    memset(out, 0, sizeof(uint32_t) * W);
+    uint32_t *queue = (uint32_t *)malloc(sizeof(uint32_t) * (V ? V : 1));
+    uint32_t head = 0, tail = 0;
+    for (uint32_t v = 0; v < V; ++v)
+        if ((seed[v >> 5] >> (v & 31) & 1u) && (in_flags[v] & F_LOADED)) {
+            out[v >> 5] |= 1u << (v & 31);
+            queue[tail++] = v;
+        }
+    uint64_t scanned = 0;
+    uint32_t lv = 0;
+    while (head < tail) {
+        uint32_t level_end = tail;
+        ++lv;
+        while (head < level_end) {
+            uint32_t v = queue[head++];
+            for (uint32_t k = rp[v]; k < rp[v + 1]; ++k) {
+                uint32_t u = cl[k];
+                ++scanned;
+                if (!(in_flags[u] & F_LOADED))
+                    continue;
+                if (out[u >> 5] >> (u & 31) & 1u)
+                    continue;
+                out[u >> 5] |= 1u << (u & 31);
+                queue[tail++] = u;
+            }
+        }
+    }
+    if (levels)
+        *levels = lv;
+    free(queue);
+    free(rrow);
+    free(rcol);
+    return scanned;
+}
+
+/* ---- safe-module name filter ---------------------------------------------
+ * Literal restatement of the first two stages of is_safe_module
+ * (reference desktop/ui.py:1391-1518): exact-name sets, then bare
+ * startswith() over the pattern list in list order.  Returns 1 when the name
+ * survives both stages (the modinfo hardware-alias stage is a separate
+ * input). */
+static const char *const ORC_CORE[] = {
+    /* kernel_core, ui.py:1402-1408 */
+    "cpuid", "msr", "acpi_pad", "acpi_cpufreq", "acpi_thermal", "dmi_sysfs", "dmi_notifier",
+    "efi_pstore", "efivars", "efivarfs", "pstore", "pstore_blk", "pstore_ram",
+    /* memory_block, ui.py:1411-1414 */
+    "zram", "zsmalloc", "loop", "nbd",
+    /* raid_dm, ui.py:1417-1421 */
+    "raid0", "raid1", "raid10", "raid456", "raid6_pq", "dm_mod", "dm_crypt", "dm_mirror",
+    "dm_snapshot", "md_mod", "linear", "multipath",
+    /* filesystems, ui.py:1424-1432 */
+    "ext4", "ext3", "ext2", "jbd2", "mbcache", "btrfs", "xfs", "jfs", "reiserfs", "minix",
+    "vfat", "fat", "msdos", "ntfs", "ntfs3", "fuse", "fuseblk", "overlayfs", "squashfs",
+    "iso9660", "udf", "nfs", "nfsd", "lockd", "exportfs", "cifs", "smb", "smbfs",
+    /* sound_core, ui.py:1435-1442 */
+    "soundcore", "snd", "snd_seq", "snd_seq_device", "snd_seq_midi", "snd_seq_midi_event",
+    "snd_timer", "snd_pcm", "snd_rawmidi", "snd_hwdep", "snd_hda_core", "snd_hda_codec",
+    "snd_hda_codec_generic", "snd_hda_intel",
+    /* hid_input_core, ui.py:1445-1450 */
+    "hid", "hid_generic", "uhid", "hidp", "usbhid", "usbkbd", "usbmouse", "joydev", "evdev",
+    "mousedev", "input_leds", "led_class",
+    /* virtualization, ui.py:1453-1459 */
+    "kvm", "kvm_intel", "kvm_amd", "vboxdrv", "vboxnetflt", "vboxnetadp", "vboxpci",
+    "vmw_balloon", "vmw_vmci", "vmw_vsock_vmci_transport", "virtio", "virtio_pci",
+    "virtio_balloon", "virtio_blk", "virtio_net", "vhost", "vhost_net", "vhost_vsock",
+    /* network_core, ui.py:1462-1465 */
+    "bridge", "stp", "llc", "bonding", "8021q", "veth", "tun", "tap",
+    /* legacy_subsystems, ui.py:1468-1470 */
+    "parport", "parport_pc", "ppdev", "lp",
+    NULL};
+
+/* dangerous_patterns, ui.py:1486-1514, list order */
+static const char *const ORC_PREFIX[] = {
+    "xt_", "nf_", "nft_", "ip_", "ip6_", "ipt_", "ip6t_", "nfnetlink", "netfilter", "conntrack",
+    "crypto_", "sha", "aes", "ghash", "crc32", "md5", "des", "ecb", "cbc", "gcm", "ccm", "ctr",
+    "k10temp", "coretemp", "ssse3", "aesni", "cpu_", "cpufreq", "intel_", "amd_", "x86_pkg_temp",
+    "acpi", "battery", "ac", "button", "fan", "thermal",
+    "i2c_", "spi_", "smbus",
+    "pcieport", "pci_bridge", "shpchp",
+    "scsi_mod", "sd_mod", "sr_mod", "sg", "st",
+    "nvme_core",
+    "videodev", "videobuf", "v4l2_common",
+    "snd_",
+    "hid_",
+    "vbox", "vmw_",
+    NULL};
+
+int orc_core_count(void)
+{
+    int n = 0;
+    while (ORC_CORE[n])
+        ++n;
+    return n;
+}
+
+int orc_prefix_count(void)
+{
+    int n = 0;
+    while (ORC_PREFIX[n])
+        ++n;
+    return n;
+}
+
+int orc_safe_name(const char *mod)
+{
+    for (int i = 0; ORC_CORE[i]; ++i)
+        if (strcmp(mod, ORC_CORE[i]) == 0)
+            return 0;
+    for (int i = 0; ORC_PREFIX[i]; ++i)
+        if (strncmp(mod, ORC_PREFIX[i], strlen(ORC_PREFIX[i])) == 0)
+            return 0;
+    return 1;
+}
+
+/* hardware-alias stage, ui.py:1537-1553: any line of the alias text, stripped,
+ * starts with one of the six bus tags.  `aliases` is the text modinfo would
+ * print (one alias per line); empty text means "no aliases" (ui.py:1533). */
+int orc_has_hw_alias(const char *aliases)
+{
+    static const char *const tags[] = {"pci:", "usb:", "platform:", "hid:", "serio:", "of:", NULL};
+    const char *p = aliases;
+    while (*p) {
+        const char *e = strchr(p, '\n');
+        size_t n = e ? (size_t)(e - p) : strlen(p);
+        size_t b = 0;
+        while (b < n && (p[b] == ' ' || p[b] == '\t' || p[b] == '\r' || p[b] == '\v' || p[b] == '\f'))
+            ++b;
+        for (int t = 0; tags[t]; ++t) {
+            size_t tl = strlen(tags[t]);
+            if (n - b >= tl && memcmp(p + b, tags[t], tl) == 0)
+                return 1;
+        }
+        if (!e)
+            break;
+        p = e + 1;
+    }
+    return 0;
+}
