@@ -1,0 +1,230 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and - at full BASELINE sizes -
+through size-independent properties.  Bit-exact: everything here is integer work."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from montecarlo_amd import McxError, synth
+from montecarlo_amd.binding import pack_strings
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NO_MATCH = 0xFFFFFFFF
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def check_k1(ctx, oracle_mod, A, a_off, a_mod, S, s_off, flags=0, sample=None):
+    ctx.alias_table_load(A, a_off, a_mod, flags)
+    first, count = ctx.alias_match(S, s_off)
+    N = len(s_off) - 1
+    idx = range(N) if sample is None else sample
+    if sample is None:
+        o_first, o_count = oracle_mod.alias_match(A, a_off, S, s_off, normalize_dash=bool(flags & 1))
+        assert np.array_equal(first, o_first)
+        assert np.array_equal(count, o_count)
+    else:
+        for i in idx:
+            f, c = oracle_mod.alias_match(A, a_off, S, s_off, normalize_dash=bool(flags & 1), i0=i, i1=i + 1)
+            assert first[i] == f[0] and count[i] == c[0], i
+    return first, count
+
+
+# ---- K1 ------------------------------------------------------------------------
+
+def test_k1_fnmatch_kat(gpu_ctx, oracle_mod):
+    """every known-answer vector, all strings x all patterns"""
+    kat = load("fnmatch_kat.json")["cases"]
+    pats = sorted({c["pattern"] for c in kat})
+    strs = sorted({c["string"] for c in kat})
+    pb = [bytes.fromhex(p) for p in pats]
+    sb = [bytes.fromhex(s) for s in strs]
+    A, a_off = pack_strings(pb)
+    S, s_off = pack_strings(sb)
+    a_mod = np.arange(len(pb), dtype=np.uint32)
+    check_k1(gpu_ctx, oracle_mod, A, a_off, a_mod, S, s_off)
+    # and each vector on its own through first_idx/count of a one-pattern table
+    for c in kat[:40]:
+        A1, a1 = pack_strings([bytes.fromhex(c["pattern"])])
+        S1, s1 = pack_strings([bytes.fromhex(c["string"])])
+        gpu_ctx.alias_table_load(A1, a1, np.zeros(1, np.uint32))
+        f, n = gpu_ctx.alias_match(S1, s1)
+        assert n[0] == c["match"] and f[0] == (0 if c["match"] else NO_MATCH)
+
+
+def test_k1_kmod_fixture(gpu_ctx, oracle_mod):
+    fx = load("kmod_resolve.json")
+    pats = [a[0].encode() for a in fx["aliases"]]
+    mods = [a[1] for a in fx["aliases"]]
+    A, a_off = pack_strings(pats)
+    S, s_off = pack_strings([q["query"].encode() for q in fx["queries"]])
+    first, count = check_k1(gpu_ctx, oracle_mod, A, a_off, np.arange(len(pats), dtype=np.uint32), S, s_off, flags=1)
+    for i, q in enumerate(fx["queries"]):
+        assert count[i] == len(q["modules"])
+        if q["modules"]:
+            assert mods[first[i]] == q["modules"][0]
+
+
+@pytest.mark.parametrize("seed,P,N", [(2, 30000, 1000), (5, 777, 130), (6, 63, 1), (7, 5, 65), (8, 4096, 64)])
+def test_k1_synthetic_vs_oracle(gpu_ctx, oracle_mod, seed, P, N):
+    """configs[1] (1000 x 30000, seed 2) and ragged shapes around the tile sizes"""
+    A, a_off, a_mod = synth.alias_table(seed, P)
+    S, s_off = synth.modalias_strings(seed, P, N)
+    first, count = check_k1(gpu_ctx, oracle_mod, A, a_off, a_mod, S, s_off)
+    if N >= 100:
+        assert (count > 0).mean() > 0.6
+
+
+def test_k1_edge_cases(gpu_ctx, oracle_mod):
+    # empty batch
+    A, a_off, a_mod = synth.alias_table(3, 100)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    f, c = gpu_ctx.alias_match(np.zeros(0, np.uint8), np.zeros(1, np.uint32))
+    assert len(f) == 0 and len(c) == 0
+    # empty strings, strings shorter than the 16-byte prefilter window, a 20 KB string
+    # (one tile then exceeds the LDS staging buffer and is read in place)
+    strs = [b"", b"p", b"pci:", b"pci:v0000", b"*", b"?", b"[", b"x" * 20000, b"pci:v" + b"0" * 3000, b""]
+    pats = [b"", b"*", b"?", b"p*", b"pci:*", b"pci:v0000", b"x*x", b"*x", b"[px]*", b"pci:v0*0", b"\\*", b"\\?",
+            b"\\[", b"[[]", b"????", b"*?", b"pci:v" + b"0" * 3000, b"pci:v" + b"0" * 2999 + b"[0-9]"]
+    A, a_off = pack_strings(pats)
+    S, s_off = pack_strings(strs)
+    check_k1(gpu_ctx, oracle_mod, A, a_off, np.arange(len(pats), dtype=np.uint32), S, s_off)
+    # empty table
+    gpu_ctx.alias_table_load(np.zeros(0, np.uint8), np.zeros(1, np.uint32), np.zeros(0, np.uint32))
+    f, c = gpu_ctx.alias_match(S, s_off)
+    assert (f == NO_MATCH).all() and (c == 0).all()
+
+
+def test_k1_random_metachar_tables(gpu_ctx, oracle_mod):
+    """random patterns heavy in metacharacters (those the compiler accepts)"""
+    import random
+
+    rnd = random.Random(5)
+    tw = oracle_mod.twin()
+    pats = []
+    while len(pats) < 600:
+        p = bytes(rnd.choice(b"ab[]!^-\\*?c") for _ in range(rnd.randint(0, 9)))
+        if tw.twin_compile_check(p, len(p), 0) == 0:
+            pats.append(p)
+    strs = [bytes(rnd.choice(b"ab[]-\\c!^*?") for _ in range(rnd.randint(0, 7))) for _ in range(300)]
+    A, a_off = pack_strings(pats)
+    S, s_off = pack_strings(strs)
+    first, count = check_k1(gpu_ctx, oracle_mod, A, a_off, np.arange(len(pats), dtype=np.uint32), S, s_off)
+    assert count.sum() > 1000
+
+
+def test_k1_rejects_unsupported_pattern(gpu_ctx):
+    A, a_off = pack_strings([b"ok*", b"[[:alpha:]]x"])
+    with pytest.raises(McxError) as e:
+        gpu_ctx.alias_table_load(A, a_off, np.zeros(2, np.uint32))
+    assert e.value.rc == -5 and "pattern 1" in str(e.value)
+
+
+def test_k1_properties_large(gpu_ctx, oracle_mod):
+    """100000 x 30000 (3e9 pairs, far beyond what the oracle finishes in seconds):
+    spot-check 48 strings against the oracle, and check the properties that hold at
+    any size: an instance of pattern j matches j; results do not depend on how the
+    batch is cut; driver_mod = a_mod[first_idx]; table order decides first_idx."""
+    seed, P, N = 4, 30000, 100000
+    A, a_off, a_mod = synth.alias_table(seed, P)
+    S, s_off = synth.modalias_strings(seed, P, N)
+    first, count = check_k1(gpu_ctx, oracle_mod, A, a_off, a_mod, S, s_off, sample=range(0, N, N // 48))
+    assert ((first == NO_MATCH) == (count == 0)).all()
+    assert (count > 0).mean() > 0.69
+    # the same strings in two halves and in reverse order
+    h = N // 2
+    f1, c1 = gpu_ctx.alias_match(S[: s_off[h]], s_off[: h + 1])
+    f2, c2 = gpu_ctx.alias_match(S[s_off[h]:], s_off[h:] - s_off[h])
+    assert np.array_equal(np.concatenate([f1, f2]), first) and np.array_equal(np.concatenate([c1, c2]), count)
+    # device-resident variant + derived driver module
+    d_S, d_off = gpu_ctx.to_device(S), gpu_ctx.to_device(s_off)
+    d_f, d_c, d_m = gpu_ctx.alloc(4 * N), gpu_ctx.alloc(4 * N), gpu_ctx.alloc(4 * N)
+    gpu_ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, d_f.ptr, d_c.ptr)
+    gpu_ctx.alias_driver_mod_dev(d_f.ptr, N, d_m.ptr)
+    assert np.array_equal(d_f.download(np.uint32, N), first)
+    assert np.array_equal(d_c.download(np.uint32, N), count)
+    mod = d_m.download(np.uint32, N)
+    want = np.where(first == NO_MATCH, NO_MATCH, a_mod[np.minimum(first, P - 1)])
+    assert np.array_equal(mod, want)
+    for b in (d_S, d_off, d_f, d_c, d_m):
+        b.free()
+
+
+def test_k1_hw_flags(gpu_ctx):
+    pats = [b"pci:v*", b"acpi*:PNP0C09:*", b"usb:v1*", b"input:b*", b" of:N*", b"xpci:v", b"serio:ty*", b"hid:b*",
+            b"platform:x"]
+    a_mod = np.array([0, 1, 1, 2, 3, 4, 5, 7, 7], dtype=np.uint32)
+    A, a_off = pack_strings(pats)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    assert gpu_ctx.alias_hw_flags(9).tolist() == [1, 1, 0, 1, 0, 1, 0, 1, 0]
+
+
+# ---- K2 ------------------------------------------------------------------------
+
+def check_k2(ctx, oracle_mod, rowptr, col, flags, seeds):
+    ctx.dep_graph_load(rowptr, col)
+    out, ref = ctx.dep_flags(flags)
+    o_out, o_ref = oracle_mod.dep_flags(rowptr, col, flags)
+    assert np.array_equal(out, o_out) and np.array_equal(ref, o_ref)
+    out2, none = ctx.dep_flags(flags, want_refcnt=False)
+    assert none is None and np.array_equal(out2, o_out)
+    for direction in (0, 1):
+        clo, edges, levels = ctx.dep_closure(flags, seeds, direction)
+        o_clo, o_edges, o_levels = oracle_mod.dep_closure(rowptr, col, flags, seeds, direction)
+        assert np.array_equal(clo, o_clo)
+        assert edges == o_edges and levels == o_levels
+    return out
+
+
+@pytest.mark.parametrize("seed,V,deg,nseed", [(3, 1000, 8, 3), (4, 50000, 10, 8), (5, 33, 3, 2), (6, 1, 1, 1)])
+def test_k2_vs_oracle(gpu_ctx, oracle_mod, seed, V, deg, nseed):
+    rowptr, col = synth.dep_graph(seed, V, deg)
+    flags = synth.dep_flags(seed, rowptr, col, 100)
+    seeds, _ = synth.seed_bitmap(seed, flags, nseed)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
+
+
+def test_k2_hand_graphs(gpu_ctx, oracle_mod):
+    # chain, diamond, isolated vertices, nothing loaded, everything seeded
+    rowptr = np.array([0, 0, 1, 2, 3], dtype=np.uint32)
+    col = np.array([0, 1, 2], dtype=np.uint32)
+    for flags in ([5, 5, 5, 7], [5, 5, 4, 7], [0, 0, 0, 0], [1, 1, 1, 1]):
+        f = np.array(flags, dtype=np.uint8)
+        for seed_word in (0, 2, 0xF):
+            check_k2(gpu_ctx, oracle_mod, rowptr, col, f, np.array([seed_word], dtype=np.uint32))
+    rowptr = np.array([0, 0, 1, 2, 4, 4, 4], dtype=np.uint32)
+    col = np.array([0, 0, 1, 2], dtype=np.uint32)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, np.array([5, 5, 5, 5, 7, 0], np.uint8), np.array([1], np.uint32))
+    # empty graph
+    gpu_ctx.dep_graph_load(np.zeros(1, np.uint32), np.zeros(0, np.uint32))
+
+
+def test_k2_full_size(gpu_ctx, oracle_mod):
+    """configs[2]: 1M modules, ~10M edges.  The oracle still finishes in seconds, so
+    this is a direct comparison plus the closure properties (idempotence, seeds
+    inside, closed under the edge relation among loaded modules)."""
+    V = 1_000_000
+    rowptr, col = synth.dep_graph(3, V, 10)
+    assert 8_000_000 < len(col) < 12_000_000
+    flags = synth.dep_flags(3, rowptr, col)
+    seeds, _ = synth.seed_bitmap(3, flags, 16)
+    out = check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
+    loaded = (flags & 1) != 0
+    assert ((out & 4) != 0).sum() > 0 and not ((out != 0) & ~loaded).any()
+    # idempotence: the closure of a closure is itself
+    clo, _, _ = gpu_ctx.dep_closure(flags, seeds, 0)
+    clo2, _, _ = gpu_ctx.dep_closure(flags, clo, 0)
+    assert np.array_equal(clo, clo2)
+    bits = np.unpackbits(clo.view(np.uint8), bitorder="little")[:V].astype(bool)
+    sbits = np.unpackbits(seeds.view(np.uint8), bitorder="little")[:V].astype(bool)
+    assert not (sbits & loaded & ~bits).any()
+    # closed: a loaded holder u of a member v is a member
+    src = np.repeat(np.arange(V, dtype=np.uint32), np.diff(rowptr))
+    viol = bits[col] & loaded[src] & ~bits[src]
+    assert not viol.any()
