@@ -19,6 +19,7 @@
  */
 #include "glob_compile.h"
 
+#include <algorithm>
 #include <array>
 #include <map>
 #include <string.h>
@@ -122,12 +123,8 @@ matched:
     return BR_MATCH;
 }
 
-enum { M_LIT, M_ANY, M_SET };
-struct Matcher {
-    uint8_t kind;
-    uint8_t byte;
-    uint16_t set;
-};
+enum { M_LIT = MCX_M_LIT, M_ANY = MCX_M_ANY, M_SET = MCX_M_SET };
+typedef mcx_matcher Matcher;
 
 static int intern_set(mcx_compiled_table &t, const std::array<uint32_t, 8> &bits, uint32_t *id)
 {
@@ -143,12 +140,6 @@ static int intern_set(mcx_compiled_table &t, const std::array<uint32_t, 8> &bits
     t.set_ids.emplace(bits, nid);
     *id = nid;
     return 0;
-}
-
-static void put16(std::vector<uint8_t> &v, uint32_t x)
-{
-    v.push_back((uint8_t)(x & 0xFF));
-    v.push_back((uint8_t)((x >> 8) & 0xFF));
 }
 
 static bool is_space(unsigned c)
@@ -171,10 +162,18 @@ static uint8_t hw_tag_of(const uint8_t *pat, size_t n)
     return 0;
 }
 
+static bool nseg_too_long(const mcx_pattern_ir &ir)
+{
+    for (const auto &sg : ir.segs)
+        if (sg.size() > 0xFFFFu)
+            return true;
+    return false;
+}
+
 } // namespace
 
-int mcx_compile_pattern(const uint8_t *pat_in, size_t n, bool normalize_dash,
-                        mcx_compiled_table &out, std::string &err)
+int mcx_parse_pattern(const uint8_t *pat_in, size_t n, bool normalize_dash, mcx_compiled_table &out,
+                      mcx_pattern_ir &ir, std::string &err)
 {
     if (n > MCX_MAX_PATTERN_BYTES) {
         err = "pattern longer than 4096 bytes";
@@ -322,79 +321,133 @@ int mcx_compile_pattern(const uint8_t *pat_in, size_t n, bool normalize_dash,
     uint32_t minlen = 0;
     for (auto &sg : segs)
         minlen += (uint32_t)sg.size();
-
-    /* emit */
-    if (out.prog_off.empty())
-        out.prog_off.push_back(0);
-    put16(out.prog, minlen);
-    out.prog.push_back((uint8_t)flags);
-    out.prog.push_back((uint8_t)segs.size());
-    for (auto &sg : segs) {
-        std::vector<uint8_t> code;
-        for (const Matcher &m : sg) {
-            if (m.kind == M_ANY) {
-                code.push_back(MCX_OP_ANY);
-            } else if (m.kind == M_SET) {
-                code.push_back(MCX_OP_SET);
-                put16(code, m.set);
-            } else if (m.byte <= 3) {
-                code.push_back(MCX_OP_ESC);
-                code.push_back(m.byte);
-            } else {
-                code.push_back(m.byte);
-            }
-        }
-        put16(out.prog, (uint32_t)sg.size());
-        put16(out.prog, (uint32_t)code.size());
-        out.prog.insert(out.prog.end(), code.begin(), code.end());
-    }
-    while (out.prog.size() & 3u)
-        out.prog.push_back(0);
-    out.prog_off.push_back((uint32_t)out.prog.size());
-
-    /* prefilter record: leading literal bytes of the anchored segment */
-    mcx_prefix_t pf;
-    memset(&pf, 0, sizeof pf);
-    uint8_t *pb = (uint8_t *)pf.pfx, *mb = (uint8_t *)pf.mask;
-    if (never) {
-        mb[0] = 0xFF; /* first byte must be NUL: only the empty string gets
-                         through, and the program itself refuses it */
-    } else {
-        const std::vector<Matcher> &s0 = segs[0];
-        for (size_t k = 0; k < s0.size() && k < MCX_PREFIX_BYTES; ++k) {
-            if (s0[k].kind != M_LIT)
-                break;
-            pb[k] = s0[k].byte;
-            mb[k] = 0xFF;
-        }
-    }
-    out.prefix.push_back(pf);
-    out.meta.push_back(MCX_META(minlen, flags));
-    out.hw_tag.push_back(hw_tag_of(pat_in, n));
+    ir.segs.swap(segs);
+    ir.flags = flags;
+    ir.minlen = minlen;
     return 0;
 }
+
+void mcx_emit_program(const mcx_pattern_ir &ir, std::vector<uint32_t> &prog)
+{
+    prog.push_back(MCX_HDR(ir.minlen, ir.flags, ir.segs.size()));
+    for (const auto &sg : ir.segs) {
+        uint32_t nchars = (uint32_t)sg.size(), nchunks = (nchars + 3u) / 4u;
+        std::vector<uint32_t> setlist;
+        std::vector<uint32_t> chunks(2 * (size_t)nchunks, 0u);
+        for (uint32_t k = 0; k < nchars; ++k) {
+            const Matcher &m = sg[k];
+            uint32_t sh = (k & 3u) * 8u;
+            if (m.kind == M_LIT) {
+                chunks[2 * (k / 4)] |= (uint32_t)m.byte << sh;
+                chunks[2 * (k / 4) + 1] |= 0xFFu << sh;
+            } else if (m.kind == M_SET) {
+                setlist.push_back(k | ((uint32_t)m.set << 16));
+            }
+        }
+        prog.push_back(nchars | ((uint32_t)setlist.size() << 16));
+        prog.insert(prog.end(), chunks.begin(), chunks.end());
+        prog.insert(prog.end(), setlist.begin(), setlist.end());
+    }
+}
+
+namespace {
+/* literal prefix of the anchored segment, at most MCX_KEY_MAX bytes */
+static std::string key_of(const mcx_pattern_ir &ir)
+{
+    std::string k;
+    for (const Matcher &m : ir.segs[0]) {
+        if (m.kind != M_LIT || k.size() >= MCX_KEY_MAX)
+            break;
+        k.push_back((char)m.byte);
+    }
+    return k;
+}
+} // namespace
 
 int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
                       bool normalize_dash, mcx_compiled_table &out, std::string &err)
 {
     out = mcx_compiled_table();
-    out.prog_off.reserve((size_t)P + 1);
-    out.prefix.reserve(P);
-    out.meta.reserve(P);
-    out.hw_tag.reserve(P);
-    out.prog_off.push_back(0);
+    out.P = P;
+    out.hw_tag.resize(P);
+    std::vector<mcx_pattern_ir> irs(P);
+    std::vector<std::string> keys(P);
+    std::vector<uint32_t> order;
+    order.reserve(P);
     for (uint32_t j = 0; j < P; ++j) {
         if (a_off[j + 1] < a_off[j]) {
             err = "a_off not monotonic at pattern " + std::to_string(j);
             return MCX_E_BAD_ARG;
         }
+        const uint8_t *pat = (const uint8_t *)arena + a_off[j];
+        size_t n = (size_t)(a_off[j + 1] - a_off[j]);
         std::string e;
-        int rc = mcx_compile_pattern((const uint8_t *)arena + a_off[j],
-                                     (size_t)(a_off[j + 1] - a_off[j]), normalize_dash, out, e);
+        int rc = mcx_parse_pattern(pat, n, normalize_dash, out, irs[j], e);
         if (rc != 0) {
             err = "pattern " + std::to_string(j) + ": " + e;
             return rc;
         }
+        out.hw_tag[j] = hw_tag_of(pat, n);
+        if (nseg_too_long(irs[j])) {
+            err = "pattern " + std::to_string(j) + ": segment longer than 65535 bytes";
+            return MCX_E_PATTERN;
+        }
+        if (irs[j].flags & MCX_PF_NEVER)
+            continue; /* matches nothing: never a candidate */
+        keys[j] = key_of(irs[j]);
+        order.push_back(j);
+    }
+    /* index order: by key length, then key bytes, then table position */
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (keys[x].size() != keys[y].size())
+            return keys[x].size() < keys[y].size();
+        int c = keys[x].compare(keys[y]);
+        if (c != 0)
+            return c < 0;
+        return x < y;
+    });
+    size_t n_idx = order.size();
+    out.orig.assign(order.begin(), order.end());
+    out.prog_off.reserve(n_idx + 1);
+    struct Group {
+        uint32_t start, count;
+    };
+    std::vector<Group> groups;
+    for (size_t k = 0; k < n_idx; ++k) {
+        uint32_t j = order[k];
+        if (k == 0 || keys[j] != keys[order[k - 1]]) {
+            groups.push_back(Group{(uint32_t)k, 0});
+            if (out.lens.empty() || out.lens.back() != keys[j].size())
+                out.lens.push_back((uint32_t)keys[j].size());
+        }
+        groups.back().count++;
+        out.prog_off.push_back((uint32_t)out.prog.size());
+        mcx_emit_program(irs[j], out.prog);
+    }
+    out.prog_off.push_back((uint32_t)out.prog.size());
+    /* hash table: at least twice as many slots as groups, never empty */
+    size_t cap = 16;
+    while (cap < 2 * groups.size())
+        cap *= 2;
+    out.slots.assign(cap, mcx_slot_t{0, 0, 0, 0});
+    for (const Group &g : groups) {
+        const std::string &key = keys[order[g.start]];
+        uint32_t a, b;
+        mcx_hash_init(a, b);
+        for (unsigned char ch : key)
+            mcx_hash_byte(a, b, ch);
+        mcx_hash_finish(a, b, (uint32_t)key.size());
+        size_t at = a & (cap - 1);
+        while (out.slots[at].count != 0) {
+            if (out.slots[at].h1 == a && out.slots[at].h2 == b) {
+                /* two different keys with one 64-bit hash: a probe would see
+                 * only the first group, so refuse rather than miss matches */
+                err = "prefix-index hash collision";
+                return MCX_E_PATTERN;
+            }
+            at = (at + 1) & (cap - 1);
+        }
+        out.slots[at] = mcx_slot_t{a, b, g.start, g.count};
     }
     return 0;
 }

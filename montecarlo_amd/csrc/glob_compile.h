@@ -1,6 +1,7 @@
 /*
  * glob_compile.h - host-side compiler from fnmatch(3) pattern text to the
- * segment programs of mcx_prog.h.  Runs once per table load.
+ * segment programs of mcx_prog.h, and builder of the literal-prefix index the
+ * device probes.  Runs once per table load.
  */
 #ifndef MCX_GLOB_COMPILE_H
 #define MCX_GLOB_COMPILE_H
@@ -13,22 +14,43 @@
 
 #include "mcx_prog.h"
 
-struct mcx_compiled_table {
-    std::vector<uint8_t> prog;        /* all programs, each 4-byte aligned     */
-    std::vector<uint32_t> prog_off;   /* P+1 byte offsets into prog            */
-    std::vector<mcx_prefix_t> prefix; /* P prefilter records                   */
-    std::vector<uint32_t> meta;       /* P words, MCX_META(minlen, flags)      */
-    std::vector<uint32_t> sets;       /* distinct bracket sets, 8 words each   */
-    std::map<std::array<uint32_t, 8>, uint32_t> set_ids; /* set bits -> number */
-    std::vector<uint8_t> hw_tag;      /* P bytes: pattern text starts with one
-                                         of the six hardware bus tags          */
+enum { MCX_M_LIT = 0, MCX_M_ANY = 1, MCX_M_SET = 2 };
+struct mcx_matcher {
+    uint8_t kind;
+    uint8_t byte;
+    uint16_t set;
 };
 
-/* Compile one pattern; appends to out.  Returns 0 or MCX_E_PATTERN and sets
- * err.  normalize_dash applies kmod's '-' -> '_' rule outside [...]. */
-int mcx_compile_pattern(const uint8_t *pat, size_t n, bool normalize_dash,
-                        mcx_compiled_table &out, std::string &err);
+/* one parsed pattern */
+struct mcx_pattern_ir {
+    std::vector<std::vector<mcx_matcher>> segs; /* segs[0] is the anchored one */
+    uint32_t flags = 0;                         /* MCX_PF_* */
+    uint32_t minlen = 0;
+};
 
+struct mcx_compiled_table {
+    uint32_t P = 0;                  /* patterns in the source table          */
+    std::vector<uint32_t> prog;      /* programs, in index order              */
+    std::vector<uint32_t> prog_off;  /* n_indexed+1 word offsets into prog    */
+    std::vector<uint32_t> orig;      /* n_indexed: table position of each     */
+    std::vector<mcx_slot_t> slots;   /* open-addressing hash table, 2^k slots */
+    std::vector<uint32_t> lens;      /* distinct key lengths, ascending       */
+    std::vector<uint32_t> sets;      /* distinct bracket sets, 8 words each   */
+    std::map<std::array<uint32_t, 8>, uint32_t> set_ids; /* set bits -> number */
+    std::vector<uint8_t> hw_tag;     /* P bytes: pattern text starts with one
+                                        of the six hardware bus tags          */
+};
+
+/* Parse one pattern.  Returns 0 or MCX_E_PATTERN and sets err.
+ * normalize_dash applies kmod's '-' -> '_' rule outside [...]. */
+int mcx_parse_pattern(const uint8_t *pat, size_t n, bool normalize_dash, mcx_compiled_table &sets_owner,
+                      mcx_pattern_ir &out, std::string &err);
+
+/* Append the program of one parsed pattern to `prog`. */
+void mcx_emit_program(const mcx_pattern_ir &ir, std::vector<uint32_t> &prog);
+
+/* Whole table: parse, group by literal prefix, emit programs in group order
+ * and build the hash index. */
 int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
                       bool normalize_dash, mcx_compiled_table &out, std::string &err);
 

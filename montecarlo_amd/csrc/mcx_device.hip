@@ -34,10 +34,14 @@ struct mcx_ctx {
     uint32_t P = 0;
     bool table_loaded = false;
     bool norm_dash = false;
-    uint8_t *d_prog = nullptr;
-    uint32_t *d_prog_off = nullptr;
-    mcx_prefix_t *d_prefix = nullptr;
-    uint32_t *d_meta = nullptr;
+    uint32_t n_indexed = 0;          /* patterns that can match anything       */
+    uint32_t *d_prog = nullptr;      /* programs in index order                */
+    uint32_t *d_prog_off = nullptr;  /* n_indexed+1 word offsets               */
+    uint32_t *d_orig = nullptr;      /* n_indexed table positions              */
+    mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
+    uint32_t slot_mask = 0;
+    uint32_t nlens = 0;
+    uint32_t lens[MCX_KEY_MAX + 1] = {0};
     uint32_t *d_sets = nullptr;
     uint32_t *d_amod = nullptr;
     uint8_t *d_hwtag = nullptr;
@@ -83,105 +87,219 @@ static int dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 /* ------------------------------------------------------------------------- */
 
 #define K1_THREADS 256
-#define K1_WAVES 4
-#define K1_TILE_STR 64
-#define K1_LDS_BYTES 16384
+#define K1_MAX_SPB 64                       /* strings per block, at most      */
+#define K1_LDS_STR_BYTES 16384              /* staging buffer for a tile       */
+#define K1_MAX_HITS (K1_MAX_SPB * (MCX_KEY_MAX + 1))
 
-typedef const __attribute__((address_space(3))) uint8_t *lds_bytes_t;
-struct LdsStr {
-    lds_bytes_t p;
-    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
+/* what the match kernel needs from the loaded table; passed by value, so the
+ * key lengths sit in the kernel argument segment */
+struct k1_table_t {
+    const uint32_t *prog;
+    const uint32_t *prog_off;
+    const uint32_t *orig;
+    const mcx_slot_t *slots;
+    const uint32_t *sets;
+    uint32_t slot_mask;
+    uint32_t nlens;
+    uint32_t lens[MCX_KEY_MAX + 1];
 };
+
+typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
+
+/* a string staged in LDS: `at` is its byte offset in the word array; the array
+ * is padded, so reading a few bytes past the string's end is safe */
+struct LdsStr {
+    lds_words_t w;
+    uint32_t at;
+    __device__ __forceinline__ uint32_t word(uint32_t q) const
+    {
+        uint32_t a = at + q, i = a >> 2;
+        return __builtin_amdgcn_alignbit(w[i + 1], w[i], (a & 3u) * 8u);
+    }
+    __device__ __forceinline__ uint32_t byte(uint32_t q) const
+    {
+        uint32_t a = at + q;
+        return (w[a >> 2] >> ((a & 3u) * 8u)) & 0xFFu;
+    }
+};
+
+/* a string read in place (tiles too long for the staging buffer): bounded
+ * byte reads, bytes past the end read as 0 */
 struct GlobalStr {
     const uint8_t *p;
-    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
+    uint32_t len;
+    __device__ __forceinline__ uint32_t byte(uint32_t q) const { return q < len ? (uint32_t)p[q] : 0u; }
+    __device__ __forceinline__ uint32_t word(uint32_t q) const
+    {
+        return byte(q) | (byte(q + 1) << 8) | (byte(q + 2) << 16) | (byte(q + 3) << 24);
+    }
 };
 
-__global__ void __launch_bounds__(256) k1_init(uint32_t *__restrict__ first, uint32_t *__restrict__ count, uint32_t N)
+/* hash of the first L bytes (L <= 32), from eight words held in registers */
+__device__ __forceinline__ void k1_key_hash(const uint32_t (&hw)[8], uint32_t L, uint32_t &a, uint32_t &b)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) {
-        first[i] = MCX_NO_MATCH;
-        count[i] = 0;
-    }
+    mcx_hash_init(a, b);
+#pragma unroll
+    for (uint32_t k = 0; k < MCX_KEY_MAX; ++k)
+        if (k < L)
+            mcx_hash_byte(a, b, (hw[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu);
+    mcx_hash_finish(a, b, L);
 }
 
 /*
- * One block = 64 strings (one per lane, the same 64 in each of the 4 waves)
- * x one tile of patterns, a quarter of the tile per wave.  The pattern index
- * is wave-uniform: prefilter records, meta words and program offsets come in
- * through scalar loads and the prefilter compares a lane's first 16 string
- * bytes against SGPR operands.  Lanes that pass run the segment program.
+ * One block = `spb` consecutive strings x the whole table.
+ *  1. the tile's bytes are staged in LDS;
+ *  2. one lane per (string, key length) hashes the string's prefix of that
+ *     length and probes the prefix index; a hit names a group of patterns
+ *     that all start with exactly those literal bytes;
+ *  3. the hits are flattened into (string, pattern) tasks, one per lane, so
+ *     that a large group costs no more per lane than a small one;
+ *  4. each task runs the pattern's segment program on its string; matches go
+ *     to per-string min / count cells in LDS, stored once at the end.
+ * The block owns its strings: no global atomics, no pre-initialised output.
  */
 __global__ void __launch_bounds__(K1_THREADS)
-k1_match_tiled(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N,
-               const mcx_prefix_t *__restrict__ prefix, const uint32_t *__restrict__ meta,
-               const uint32_t *__restrict__ prog_off, const uint8_t *__restrict__ prog,
-               const uint32_t *__restrict__ sets, uint32_t P, uint32_t pat_tile,
-               uint32_t *__restrict__ first_idx, uint32_t *__restrict__ count)
+k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
+                 uint32_t str_cap, const k1_table_t T, uint32_t *__restrict__ first_idx,
+                 uint32_t *__restrict__ count)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[K1_LDS_BYTES];
+    /* dynamic LDS, sized by the launch for its strings-per-block:
+     * [str_cap/4 + 4 words of string bytes][hit_start][hit_slot][hit_pref + 1] */
+    extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
+    __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
+    __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB];
+    __shared__ uint32_t nhits;
+    const uint32_t max_hits = spb * T.nlens;
+    uint32_t *str_w = k1_lds;
+    uint32_t *hit_start = str_w + str_cap / 4u + 4u;
+    uint32_t *hit_slot = hit_start + max_hits;
+    uint32_t *hit_pref = hit_slot + max_hits;
 
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t t0 = blockIdx.y * K1_TILE_STR;
-    const uint32_t nstr = min((uint32_t)K1_TILE_STR, N - t0);
-    const uint32_t base = s_off[t0];
-    /* a tile whose strings do not fit the staging buffer is read in place */
-    const uint32_t total = s_off[t0 + nstr] - base;
-    const bool USE_LDS = total <= K1_LDS_BYTES;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t0 = blockIdx.x * spb;
+    const uint32_t nstr = min(spb, N - t0);
+    const uint32_t gbase = s_off[t0];
+    const uint32_t total = s_off[t0 + nstr] - gbase;
+    const bool use_lds = total <= str_cap;
 
-    if (USE_LDS) {
-        for (uint32_t b = threadIdx.x; b < total; b += K1_THREADS)
-            lds[b] = S[base + b];
-        __syncthreads();
+    if (tid < nstr) {
+        uint32_t so = s_off[t0 + tid];
+        str_at[tid] = so - gbase;
+        str_len[tid] = s_off[t0 + tid + 1] - so;
+        res_first[tid] = MCX_NO_MATCH;
+        res_count[tid] = 0;
     }
-
-    const bool live = lane < nstr;
-    const uint32_t i = t0 + (live ? lane : 0u);
-    const uint32_t so = s_off[i];
-    const uint32_t len = live ? s_off[i + 1] - so : 0u;
-    const LdsStr str_lds{(lds_bytes_t)lds + (so - base)};
-    const GlobalStr str_glb{S + so};
-
-    /* first 16 bytes, zero padded: no string byte is NUL, so padding can never
-     * equal a literal */
-    uint32_t h[4] = {0, 0, 0, 0};
+    if (tid == 0)
+        nhits = 0;
+    if (use_lds) {
+        /* byte k of the buffer = byte gbase + k of the arena, then zero padding */
+        const uint32_t nwords = (total + 3u) / 4u + 3u;
+        for (uint32_t w = tid; w < nwords; w += K1_THREADS) {
+            uint32_t v = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
-        uint32_t c = 0u;
-        if (k < len)
-            c = USE_LDS ? str_lds[k] : str_glb[k];
-        h[k >> 2] |= c << ((k & 3u) * 8u);
+            for (uint32_t k = 0; k < 4; ++k) {
+                uint32_t b = 4u * w + k;
+                if (b < total)
+                    v |= (uint32_t)S[gbase + b] << (8u * k);
+            }
+            str_w[w] = v;
+        }
     }
+    __syncthreads();
 
-    const uint32_t j_tile = blockIdx.x * pat_tile;
-    const uint32_t per_wave = (pat_tile + K1_WAVES - 1) / K1_WAVES;
-    const uint32_t j_begin = j_tile + wave * per_wave;
-    const uint32_t j_end = min(min(j_begin + per_wave, j_tile + pat_tile), P);
-
-    uint32_t first = MCX_NO_MATCH, cnt = 0;
-    for (uint32_t j = j_begin; j < j_end; ++j) {
-        const mcx_prefix_t pf = prefix[j];
-        const uint32_t m = meta[j];
-        uint32_t d = ((h[0] ^ pf.pfx[0]) & pf.mask[0]) | ((h[1] ^ pf.pfx[1]) & pf.mask[1]) |
-                     ((h[2] ^ pf.pfx[2]) & pf.mask[2]) | ((h[3] ^ pf.pfx[3]) & pf.mask[3]);
-        bool pass = live && d == 0u && len >= MCX_META_MINLEN(m);
-        if (pass) {
-            bool ok;
-            if (USE_LDS)
-                ok = mcx_prog_match(prog + prog_off[j], str_lds, len, sets);
-            else
-                ok = mcx_prog_match(prog + prog_off[j], str_glb, len, sets);
-            if (ok) {
-                first = min(first, j);
-                ++cnt;
+    /* ---- probe ---------------------------------------------------------- */
+    const uint32_t nprobe = nstr * T.nlens;
+    for (uint32_t pr = tid; pr < nprobe; pr += K1_THREADS) {
+        const uint32_t slot = pr / T.nlens, L = T.lens[pr - slot * T.nlens];
+        const uint32_t len = str_len[slot];
+        if (L > len)
+            continue;
+        uint32_t hw[8];
+        if (use_lds) {
+            LdsStr str{(lds_words_t)str_w, str_at[slot]};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+                hw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
+        } else {
+            GlobalStr str{S + gbase + str_at[slot], len};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+                hw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
+        }
+        uint32_t a, b;
+        k1_key_hash(hw, L, a, b);
+        for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
+            const mcx_slot_t sl = T.slots[at];
+            if (sl.count == 0u)
+                break;
+            if (sl.h1 == a && sl.h2 == b) {
+                uint32_t h = atomicAdd(&nhits, 1u);
+                hit_start[h] = sl.start;
+                hit_slot[h] = slot;
+                hit_pref[h + 1] = sl.count;
+                break;
             }
         }
     }
-    if (cnt) {
-        atomicMin(&first_idx[i], first);
-        atomicAdd(&count[i], cnt);
+    __syncthreads();
+
+    /* ---- exclusive prefix sum of the hit sizes (first wave) -------------- */
+    const uint32_t nh = nhits;
+    if (tid < 64) {
+        const uint32_t per = (nh + 63u) / 64u;
+        const uint32_t lo = tid * per, hi = min(lo + per, nh);
+        uint32_t sum = 0;
+        for (uint32_t h = lo; h < hi; ++h)
+            sum += hit_pref[h + 1];
+        uint32_t incl = sum;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d, 64);
+            if (tid >= d)
+                incl += o;
+        }
+        uint32_t run = incl - sum;
+        if (tid == 0)
+            hit_pref[0] = 0;
+        for (uint32_t h = lo; h < hi; ++h) {
+            run += hit_pref[h + 1];
+            hit_pref[h + 1] = run;
+        }
+    }
+    __syncthreads();
+
+    /* ---- tasks ----------------------------------------------------------- */
+    const uint32_t ntasks = hit_pref[nh];
+    for (uint32_t t = tid; t < ntasks; t += K1_THREADS) {
+        uint32_t lo = 0, hi = nh; /* largest h with hit_pref[h] <= t */
+        while (hi - lo > 1u) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (hit_pref[mid] <= t)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t k = hit_start[lo] + (t - hit_pref[lo]);
+        const uint32_t slot = hit_slot[lo];
+        const uint32_t len = str_len[slot];
+        const uint32_t *prog = T.prog + T.prog_off[k];
+        bool ok;
+        if (use_lds) {
+            LdsStr str{(lds_words_t)str_w, str_at[slot]};
+            ok = mcx_prog_match(prog, str, len, T.sets);
+        } else {
+            GlobalStr str{S + gbase + str_at[slot], len};
+            ok = mcx_prog_match(prog, str, len, T.sets);
+        }
+        if (ok) {
+            atomicMin(&res_first[slot], T.orig[k]);
+            atomicAdd(&res_count[slot], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < nstr) {
+        first_idx[t0 + tid] = res_first[tid];
+        count[t0 + tid] = res_count[tid];
     }
 }
 
@@ -358,20 +476,22 @@ static void free_table(mcx_ctx *ctx)
 {
     (void)hipFree(ctx->d_prog);
     (void)hipFree(ctx->d_prog_off);
-    (void)hipFree(ctx->d_prefix);
-    (void)hipFree(ctx->d_meta);
+    (void)hipFree(ctx->d_orig);
+    (void)hipFree(ctx->d_slots);
     (void)hipFree(ctx->d_sets);
     (void)hipFree(ctx->d_amod);
     (void)hipFree(ctx->d_hwtag);
     ctx->d_prog = nullptr;
     ctx->d_prog_off = nullptr;
-    ctx->d_prefix = nullptr;
-    ctx->d_meta = nullptr;
+    ctx->d_orig = nullptr;
+    ctx->d_slots = nullptr;
     ctx->d_sets = nullptr;
     ctx->d_amod = nullptr;
     ctx->d_hwtag = nullptr;
     ctx->table_loaded = false;
     ctx->P = 0;
+    ctx->n_indexed = 0;
+    ctx->nlens = 0;
     ctx->table_bytes = 0;
 }
 
@@ -500,8 +620,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     free_table(ctx);
     if ((rc = dev_upload(ctx, &ctx->d_prog, t.prog.data(), t.prog.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_prog_off, t.prog_off.data(), t.prog_off.size())) != 0 ||
-        (rc = dev_upload(ctx, &ctx->d_prefix, t.prefix.data(), t.prefix.size())) != 0 ||
-        (rc = dev_upload(ctx, &ctx->d_meta, t.meta.data(), t.meta.size())) != 0 ||
+        (rc = dev_upload(ctx, &ctx->d_orig, t.orig.data(), t.orig.size())) != 0 ||
+        (rc = dev_upload(ctx, &ctx->d_slots, t.slots.data(), t.slots.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_sets, t.sets.data(), t.sets.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_amod, a_mod, (size_t)P)) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_hwtag, t.hw_tag.data(), t.hw_tag.size())) != 0) {
@@ -510,9 +630,14 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->P = P;
+    ctx->n_indexed = (uint32_t)t.orig.size();
+    ctx->slot_mask = (uint32_t)t.slots.size() - 1u;
+    ctx->nlens = (uint32_t)t.lens.size();
+    for (uint32_t k = 0; k < ctx->nlens; ++k)
+        ctx->lens[k] = t.lens[k];
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
-    ctx->table_bytes = t.prog.size() + 4 * t.prog_off.size() + sizeof(mcx_prefix_t) * t.prefix.size() +
-                       4 * t.meta.size() + 4 * t.sets.size() + 4 * (uint64_t)P + t.hw_tag.size();
+    ctx->table_bytes = 4 * (uint64_t)(t.prog.size() + t.prog_off.size() + t.orig.size() + t.sets.size()) +
+                       sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + 4 * (uint64_t)P + t.hw_tag.size();
     ctx->table_loaded = true;
     return MCX_OK;
 }
@@ -535,24 +660,32 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
 {
     if (N == 0)
         return MCX_OK;
-    k1_init<<<(N + 255) / 256, 256, 0, ctx->stream>>>(d_first, d_count, N);
-    if (ctx->P == 0)
-        return MCX_OK;
-    uint32_t tiles_s = (N + K1_TILE_STR - 1) / K1_TILE_STR;
-    uint32_t want_p = tiles_s >= 4096 ? 1u : 4096u / tiles_s;
-    uint32_t pat_tile = (ctx->P + want_p - 1) / want_p;
-    if (pat_tile < 64)
-        pat_tile = 64;
-    pat_tile = (pat_tile + 3u) & ~3u;
-    uint32_t tiles_p = (ctx->P + pat_tile - 1) / pat_tile;
-    if (tiles_s > 65535u) {
-        ctx->err = "more than 65535*64 strings in one call";
-        return MCX_E_TOO_LARGE;
-    }
-    dim3 grid(tiles_p, tiles_s);
-    k1_match_tiled<<<grid, K1_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, ctx->d_prefix, ctx->d_meta,
-                                                          ctx->d_prog_off, ctx->d_prog, ctx->d_sets, ctx->P,
-                                                          pat_tile, d_first, d_count);
+    /* few strings: one or two per block so that the whole chip has work;
+     * many strings: 64 per block */
+    uint32_t spb = (N + 2047u) / 2048u;
+    if (spb > K1_MAX_SPB)
+        spb = K1_MAX_SPB;
+    uint32_t blocks = (N + spb - 1u) / spb;
+    k1_table_t T;
+    T.prog = ctx->d_prog;
+    T.prog_off = ctx->d_prog_off;
+    T.orig = ctx->d_orig;
+    T.slots = ctx->d_slots;
+    T.sets = ctx->d_sets;
+    T.slot_mask = ctx->slot_mask;
+    T.nlens = ctx->nlens;
+    for (uint32_t k = 0; k <= MCX_KEY_MAX; ++k)
+        T.lens[k] = k < ctx->nlens ? ctx->lens[k] : 0u;
+    /* staging buffer: 256 bytes per string of the tile, between 1 KiB and 16 KiB;
+     * a tile that needs more is read in place */
+    uint32_t str_cap = spb * 256u;
+    if (str_cap < 1024u)
+        str_cap = 1024u;
+    if (str_cap > K1_LDS_STR_BYTES)
+        str_cap = K1_LDS_STR_BYTES;
+    size_t lds = 4 * ((size_t)str_cap / 4 + 4 + 3 * (size_t)spb * T.nlens + 1);
+    k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, T, d_first,
+                                                               d_count);
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
 }

@@ -10,14 +10,21 @@
 #include <stdint.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #include "../include/mcx.h"
 #include "../montecarlo_amd/csrc/glob_compile.h"
 
 namespace {
+/* bounded reads: bytes beyond the string read as 0 (they are always masked) */
 struct HostStr {
     const uint8_t *p;
-    uint32_t operator[](uint32_t i) const { return p[i]; }
+    uint32_t len;
+    uint32_t byte(uint32_t q) const { return q < len ? p[q] : 0u; }
+    uint32_t word(uint32_t q) const
+    {
+        return byte(q) | (byte(q + 1) << 8) | (byte(q + 2) << 16) | (byte(q + 3) << 24);
+    }
 };
 
 static void normalize(std::string &s, bool *bad)
@@ -47,28 +54,29 @@ extern "C" {
 int twin_compile_check(const char *pattern, uint32_t n, int normalize_dash)
 {
     mcx_compiled_table t;
+    mcx_pattern_ir ir;
     std::string err;
-    return mcx_compile_pattern((const uint8_t *)pattern, n, normalize_dash != 0, t, err);
+    return mcx_parse_pattern((const uint8_t *)pattern, n, normalize_dash != 0, t, ir, err);
 }
 
 /* 1 = match, 0 = no match, <0 = pattern rejected */
 int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t sn)
 {
     mcx_compiled_table t;
+    mcx_pattern_ir ir;
     std::string err;
-    int rc = mcx_compile_pattern((const uint8_t *)pattern, pn, false, t, err);
+    int rc = mcx_parse_pattern((const uint8_t *)pattern, pn, false, t, ir, err);
     if (rc != 0)
         return rc;
-    HostStr s{(const uint8_t *)string};
-    return mcx_prog_match(t.prog.data() + t.prog_off[0], s, sn,
-                          t.sets.empty() ? nullptr : t.sets.data())
-               ? 1
-               : 0;
+    std::vector<uint32_t> prog;
+    mcx_emit_program(ir, prog);
+    HostStr s{(const uint8_t *)string, sn};
+    return mcx_prog_match(prog.data(), s, sn, t.sets.empty() ? nullptr : t.sets.data()) ? 1 : 0;
 }
 
 /* Same contract as orc_alias_match; returns 0 or a negative MCX_E_* code.
- * The prefilter record is applied first, as the device does, so that it is
- * covered too. */
+ * Candidates come from the literal-prefix index, probed the way the device
+ * probes it, so the index is covered too. */
 int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const char *S,
                      const uint32_t *s_off, uint32_t i0, uint32_t i1, int normalize_dash,
                      uint32_t *first_idx, uint32_t *count)
@@ -79,6 +87,7 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
     if (rc != 0)
         return rc;
     const uint32_t *sets = t.sets.empty() ? nullptr : t.sets.data();
+    const size_t mask = t.slots.size() - 1;
     for (uint32_t i = i0; i < i1; ++i) {
         std::string str(S + s_off[i], S + s_off[i + 1]);
         bool bad = false;
@@ -87,21 +96,26 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
         uint32_t first = MCX_NO_MATCH, cnt = 0;
         if (!bad) {
             uint32_t len = (uint32_t)str.size();
-            uint8_t head[16] = {0};
-            memcpy(head, str.data(), len < 16 ? len : 16);
-            uint32_t h[4];
-            memcpy(h, head, 16);
-            HostStr s{(const uint8_t *)str.data()};
-            for (uint32_t j = 0; j < P; ++j) {
-                const mcx_prefix_t &pf = t.prefix[j];
-                uint32_t d = ((h[0] ^ pf.pfx[0]) & pf.mask[0]) | ((h[1] ^ pf.pfx[1]) & pf.mask[1]) |
-                             ((h[2] ^ pf.pfx[2]) & pf.mask[2]) | ((h[3] ^ pf.pfx[3]) & pf.mask[3]);
-                if (d != 0 || len < MCX_META_MINLEN(t.meta[j]))
+            HostStr s{(const uint8_t *)str.data(), len};
+            for (uint32_t L : t.lens) {
+                if (L > len)
                     continue;
-                if (mcx_prog_match(t.prog.data() + t.prog_off[j], s, len, sets)) {
-                    if (first == MCX_NO_MATCH)
-                        first = j;
-                    ++cnt;
+                uint32_t a, b;
+                mcx_hash_init(a, b);
+                for (uint32_t k = 0; k < L; ++k)
+                    mcx_hash_byte(a, b, s.byte(k));
+                mcx_hash_finish(a, b, L);
+                for (size_t at = a & mask; t.slots[at].count != 0; at = (at + 1) & mask) {
+                    const mcx_slot_t &sl = t.slots[at];
+                    if (sl.h1 != a || sl.h2 != b)
+                        continue;
+                    for (uint32_t k = sl.start; k < sl.start + sl.count; ++k)
+                        if (mcx_prog_match(t.prog.data() + t.prog_off[k], s, len, sets)) {
+                            if (t.orig[k] < first)
+                                first = t.orig[k];
+                            ++cnt;
+                        }
+                    break;
                 }
             }
         }
