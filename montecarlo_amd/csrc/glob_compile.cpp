@@ -362,6 +362,40 @@ static std::string key_of(const mcx_pattern_ir &ir)
     }
     return k;
 }
+
+/* up to four Bloom bits of the pattern's grams, preferring grams that are not
+ * wholly inside the index key (every string that reaches the pattern through
+ * the index already starts with the key) */
+static uint32_t sig_of(const mcx_pattern_ir &ir, size_t keylen)
+{
+    std::vector<uint32_t> bits;
+    for (size_t si = 0; si < ir.segs.size(); ++si) {
+        const auto &sg = ir.segs[si];
+        for (size_t k = 0; k + 4 <= sg.size(); ++k) {
+            if (sg[k].kind != M_LIT || sg[k + 1].kind != M_LIT || sg[k + 2].kind != M_LIT ||
+                sg[k + 3].kind != M_LIT)
+                continue;
+            if (si == 0 && k + 4 <= keylen)
+                continue;
+            uint32_t g = (uint32_t)sg[k].byte | ((uint32_t)sg[k + 1].byte << 8) |
+                         ((uint32_t)sg[k + 2].byte << 16) | ((uint32_t)sg[k + 3].byte << 24);
+            uint32_t b = mcx_gram_bit(g);
+            if (std::find(bits.begin(), bits.end(), b) == bits.end())
+                bits.push_back(b);
+        }
+    }
+    uint32_t sig = 0;
+    for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t b = MCX_BLOOM_FREE;
+        if (!bits.empty()) {
+            /* spread the picks over the list */
+            size_t n = bits.size();
+            b = n <= 4 ? (k < n ? bits[k] : bits[0]) : bits[(k * (n - 1)) / 3];
+        }
+        sig |= b << (8u * k);
+    }
+    return sig;
+}
 } // namespace
 
 int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
@@ -408,7 +442,9 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     });
     size_t n_idx = order.size();
     out.orig.assign(order.begin(), order.end());
-    out.prog_off.reserve(n_idx + 1);
+    out.slot.assign(n_idx * (size_t)MCX_SLOT_WORDS, 0u);
+    out.sig.resize(n_idx);
+    std::vector<uint32_t> one;
     struct Group {
         uint32_t start, count;
     };
@@ -421,10 +457,18 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
                 out.lens.push_back((uint32_t)keys[j].size());
         }
         groups.back().count++;
-        out.prog_off.push_back((uint32_t)out.prog.size());
-        mcx_emit_program(irs[j], out.prog);
+        one.clear();
+        mcx_emit_program(irs[j], one);
+        uint32_t *sl = &out.slot[k * (size_t)MCX_SLOT_WORDS];
+        if (one.size() <= MCX_SLOT_WORDS) {
+            std::copy(one.begin(), one.end(), sl);
+        } else {
+            sl[0] = MCX_HDR(irs[j].minlen, irs[j].flags | MCX_PF_EXT, irs[j].segs.size());
+            sl[1] = (uint32_t)out.ext.size();
+            out.ext.insert(out.ext.end(), one.begin(), one.end());
+        }
+        out.sig[k] = sig_of(irs[j], keys[j].size());
     }
-    out.prog_off.push_back((uint32_t)out.prog.size());
     /* hash table: at least twice as many slots as groups, never empty */
     size_t cap = 16;
     while (cap < 2 * groups.size())
@@ -432,11 +476,9 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     out.slots.assign(cap, mcx_slot_t{0, 0, 0, 0});
     for (const Group &g : groups) {
         const std::string &key = keys[order[g.start]];
-        uint32_t a, b;
-        mcx_hash_init(a, b);
-        for (unsigned char ch : key)
-            mcx_hash_byte(a, b, ch);
-        mcx_hash_finish(a, b, (uint32_t)key.size());
+        uint32_t a, b, kw[MCX_KEY_MAX / 4] = {0};
+        memcpy(kw, key.data(), key.size());
+        mcx_key_hash(kw, (uint32_t)key.size(), a, b);
         size_t at = a & (cap - 1);
         while (out.slots[at].count != 0) {
             if (out.slots[at].h1 == a && out.slots[at].h2 == b) {

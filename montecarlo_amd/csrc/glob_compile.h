@@ -30,8 +30,9 @@ struct mcx_pattern_ir {
 
 struct mcx_compiled_table {
     uint32_t P = 0;                  /* patterns in the source table          */
-    std::vector<uint32_t> prog;      /* programs, in index order              */
-    std::vector<uint32_t> prog_off;  /* n_indexed+1 word offsets into prog    */
+    std::vector<uint32_t> slot;      /* n_indexed x MCX_SLOT_WORDS, index order */
+    std::vector<uint32_t> ext;       /* programs too long for a slot          */
+    std::vector<uint32_t> sig;       /* n_indexed gram signatures             */
     std::vector<uint32_t> orig;      /* n_indexed: table position of each     */
     std::vector<mcx_slot_t> slots;   /* open-addressing hash table, 2^k slots */
     std::vector<uint32_t> lens;      /* distinct key lengths, ascending       */

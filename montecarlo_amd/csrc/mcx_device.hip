@@ -35,8 +35,9 @@ struct mcx_ctx {
     bool table_loaded = false;
     bool norm_dash = false;
     uint32_t n_indexed = 0;          /* patterns that can match anything       */
-    uint32_t *d_prog = nullptr;      /* programs in index order                */
-    uint32_t *d_prog_off = nullptr;  /* n_indexed+1 word offsets               */
+    uint32_t *d_slot = nullptr;      /* n_indexed program slots, index order   */
+    uint32_t *d_ext = nullptr;       /* overflow programs                      */
+    uint32_t *d_sig = nullptr;       /* n_indexed gram signatures              */
     uint32_t *d_orig = nullptr;      /* n_indexed table positions              */
     mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
     uint32_t slot_mask = 0;
@@ -94,9 +95,10 @@ static int dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 /* what the match kernel needs from the loaded table; passed by value, so the
  * key lengths sit in the kernel argument segment */
 struct k1_table_t {
-    const uint32_t *prog;
-    const uint32_t *prog_off;
-    const uint32_t *orig;
+    const uint32_t *slot;   /* n_indexed x MCX_SLOT_WORDS                       */
+    const uint32_t *ext;    /* overflow programs                               */
+    const uint32_t *sig;    /* n_indexed gram signatures                       */
+    const uint32_t *orig;   /* n_indexed table positions                       */
     const mcx_slot_t *slots;
     const uint32_t *sets;
     uint32_t slot_mask;
@@ -135,99 +137,176 @@ struct GlobalStr {
     }
 };
 
-/* hash of the first L bytes (L <= 32), from eight words held in registers */
-__device__ __forceinline__ void k1_key_hash(const uint32_t (&hw)[8], uint32_t L, uint32_t &a, uint32_t &b)
-{
-    mcx_hash_init(a, b);
-#pragma unroll
-    for (uint32_t k = 0; k < MCX_KEY_MAX; ++k)
-        if (k < L)
-            mcx_hash_byte(a, b, (hw[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu);
-    mcx_hash_finish(a, b, L);
-}
+/* a lane's program slot, copied to LDS as [word][lane] so that 64 lanes
+ * reading the same word index hit 64 different banks */
+struct LdsProg {
+    lds_words_t w;
+    uint32_t lane;
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return w[i * 64u + lane]; }
+};
+struct GlobalProg {
+    const uint32_t *p;
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
+};
+struct LdsBloom {
+    lds_words_t w;
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return w[i]; }
+};
+
+#define K1_RING 1024u       /* survivors waiting for a program run, per block    */
+#define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
+#define K1_WAVES (K1_THREADS / 64)
+
+struct __attribute__((aligned(4))) k1_sig4_t {
+    uint32_t v[4];
+};
 
 /*
- * One block = `spb` consecutive strings x the whole table.
- *  1. the tile's bytes are staged in LDS;
+ * One block (4 waves) = `spb` consecutive strings x the whole table.
+ *  1. the tile's bytes are staged in LDS and every string gets its 256-bit
+ *     gram set;
  *  2. one lane per (string, key length) hashes the string's prefix of that
- *     length and probes the prefix index; a hit names a group of patterns
- *     that all start with exactly those literal bytes;
- *  3. the hits are flattened into (string, pattern) tasks, one per lane, so
- *     that a large group costs no more per lane than a small one;
- *  4. each task runs the pattern's segment program on its string; matches go
- *     to per-string min / count cells in LDS, stored once at the end.
+ *     length and probes the prefix index; a hit names a group of patterns that
+ *     all start with exactly those literal bytes;
+ *  3. hits are cut into units of up to 256 consecutive patterns; the waves
+ *     share the units, four patterns per lane, and keep the patterns whose
+ *     gram signature is inside the string's gram set: survivors are compacted
+ *     by ballot into one ring per block;
+ *  4. survivors are run 64 at a time by as few waves as it takes (a wave with
+ *     four live lanes costs as much as one with 64): every lane copies one
+ *     survivor's program slot into LDS and runs it on its string; matches go
+ *     to per-string min / count cells in LDS, stored at the end.
  * The block owns its strings: no global atomics, no pre-initialised output.
  */
 __global__ void __launch_bounds__(K1_THREADS)
 k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
-                 uint32_t str_cap, const k1_table_t T, uint32_t *__restrict__ first_idx,
-                 uint32_t *__restrict__ count)
+                 uint32_t str_cap, uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
+                 uint32_t *__restrict__ count, uint32_t dbg_stop
+#ifdef MCX_K1_STAMPS
+                 , unsigned long long *__restrict__ stamps
+#endif
+                 )
 {
+#ifdef MCX_K1_STAMPS
+    /* diagnostic build only: shader-clock stamps at the phase boundaries */
+#define K1_STAMP(i)                                                          \
+    do {                                                                     \
+        if (threadIdx.x == 0)                                                \
+            stamps[blockIdx.x * 8u + (i)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define K1_STAMP(i) do { } while (0)
+#endif
+    K1_STAMP(0);
     /* dynamic LDS, sized by the launch for its strings-per-block:
-     * [str_cap/4 + 4 words of string bytes][hit_start][hit_slot][hit_pref + 1] */
+     * [str_cap/4 + 5 words of string bytes][hit_start][hit_slot][hit_cnt][hit_upref + 1] */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
+    __shared__ uint32_t progc[K1_WAVES][MCX_SLOT_WORDS * 64];
+    __shared__ uint32_t ring[K1_RING];
+    __shared__ uint32_t bloom[K1_MAX_SPB][MCX_BLOOM_WORDS];
     __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
     __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB];
-    __shared__ uint32_t nhits;
+    __shared__ uint32_t nhits, ring_tail, ring_head;
     const uint32_t max_hits = spb * T.nlens;
     uint32_t *str_w = k1_lds;
-    uint32_t *hit_start = str_w + str_cap / 4u + 4u;
+    uint32_t *hit_start = str_w + str_cap / 4u + 5u;
     uint32_t *hit_slot = hit_start + max_hits;
-    uint32_t *hit_pref = hit_slot + max_hits;
+    uint32_t *hit_cnt = hit_slot + max_hits;
+    uint32_t *hit_upref = hit_cnt + max_hits;
 
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t t0 = blockIdx.x * spb;
     const uint32_t nstr = min(spb, N - t0);
     const uint32_t gbase = s_off[t0];
-    const uint32_t total = s_off[t0 + nstr] - gbase;
+    const uint32_t gend = s_off[t0 + nstr];
+    const uint32_t arena_end = s_off[N];
+    const uint32_t total = gend - gbase;
     const bool use_lds = total <= str_cap;
+    /* with a 4-byte aligned arena the tile is copied word by word from the
+     * aligned address below its first byte; `shift` bytes of the previous
+     * string then sit in front of it in the buffer */
+    const uint32_t shift = (use_lds && s_aligned) ? (gbase & 3u) : 0u;
 
-    if (tid < nstr) {
-        uint32_t so = s_off[t0 + tid];
-        str_at[tid] = so - gbase;
-        str_len[tid] = s_off[t0 + tid + 1] - so;
-        res_first[tid] = MCX_NO_MATCH;
-        res_count[tid] = 0;
+    for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
+        uint32_t so = s_off[t0 + i];
+        str_at[i] = so - gbase + shift;
+        str_len[i] = s_off[t0 + i + 1] - so;
+        res_first[i] = MCX_NO_MATCH;
+        res_count[i] = 0;
     }
-    if (tid == 0)
+    for (uint32_t w = tid; w < nstr * MCX_BLOOM_WORDS; w += K1_THREADS) {
+        /* strings read in place get a full set: their patterns are not screened */
+        uint32_t v = use_lds ? 0u : 0xFFFFFFFFu;
+        if ((w & (MCX_BLOOM_WORDS - 1u)) == (MCX_BLOOM_FREE >> 5))
+            v |= 1u << (MCX_BLOOM_FREE & 31u);
+        bloom[w / MCX_BLOOM_WORDS][w & (MCX_BLOOM_WORDS - 1u)] = v;
+    }
+    if (tid == 0) {
         nhits = 0;
+        ring_tail = 0;
+        ring_head = 0;
+    }
     if (use_lds) {
-        /* byte k of the buffer = byte gbase + k of the arena, then zero padding */
-        const uint32_t nwords = (total + 3u) / 4u + 3u;
+        const uint32_t a0 = gbase - shift; /* arena byte held by buffer byte 0 */
+        const uint32_t nwords = (total + shift + 3u) / 4u + 3u;
         for (uint32_t w = tid; w < nwords; w += K1_THREADS) {
+            const uint32_t b0 = a0 + 4u * w;
             uint32_t v = 0;
+            if (s_aligned && b0 + 4u <= arena_end) {
+                v = *(const uint32_t *)(S + b0);
+            } else {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                uint32_t b = 4u * w + k;
-                if (b < total)
-                    v |= (uint32_t)S[gbase + b] << (8u * k);
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (b0 + k < arena_end)
+                        v |= (uint32_t)S[b0 + k] << (8u * k);
             }
             str_w[w] = v;
         }
     }
     __syncthreads();
+    K1_STAMP(1);
+    if (dbg_stop == 1) return;
 
-    /* ---- probe ---------------------------------------------------------- */
+    /* ---- gram sets: one wave per string, one lane per start position ------- */
+    if (use_lds) {
+        for (uint32_t slot = wave; slot < nstr; slot += K1_WAVES) {
+            const uint32_t len = str_len[slot];
+            LdsStr str{(lds_words_t)str_w, str_at[slot]};
+            for (uint32_t q = lane; q + 4u <= len; q += 64u) {
+                uint32_t bit = mcx_gram_bit(str.word(q));
+                atomicOr(&bloom[slot][bit >> 5], 1u << (bit & 31u));
+            }
+        }
+    }
+
+    /* ---- probe: last wave first, so that it overlaps the gram sets -------- */
     const uint32_t nprobe = nstr * T.nlens;
-    for (uint32_t pr = tid; pr < nprobe; pr += K1_THREADS) {
+    for (uint32_t pr = (K1_THREADS - 1u) - tid; pr < nprobe; pr += K1_THREADS) {
         const uint32_t slot = pr / T.nlens, L = T.lens[pr - slot * T.nlens];
         const uint32_t len = str_len[slot];
         if (L > len)
             continue;
-        uint32_t hw[8];
+        uint32_t kw[MCX_KEY_MAX / 4];
         if (use_lds) {
             LdsStr str{(lds_words_t)str_w, str_at[slot]};
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                hw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
+            for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                kw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
         } else {
             GlobalStr str{S + gbase + str_at[slot], len};
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                hw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
+            for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                kw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
         }
+        /* zero the bytes past L in the last word */
+#pragma unroll
+        for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+            if ((L >> 2) == k && (L & 3u))
+                kw[k] &= 0xFFFFFFFFu >> (8u * (4u - (L & 3u)));
         uint32_t a, b;
-        k1_key_hash(hw, L, a, b);
+        mcx_key_hash(kw, L, a, b);
         for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
             const mcx_slot_t sl = T.slots[at];
             if (sl.count == 0u)
@@ -236,71 +315,173 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 uint32_t h = atomicAdd(&nhits, 1u);
                 hit_start[h] = sl.start;
                 hit_slot[h] = slot;
-                hit_pref[h + 1] = sl.count;
+                hit_cnt[h] = sl.count;
                 break;
             }
         }
     }
     __syncthreads();
+    K1_STAMP(2);
+    if (dbg_stop == 2) return;
 
-    /* ---- exclusive prefix sum of the hit sizes (first wave) -------------- */
+    /* ---- exclusive prefix sum of the hits' unit counts (first wave) ------- */
     const uint32_t nh = nhits;
-    if (tid < 64) {
+    if (wave == 0) {
         const uint32_t per = (nh + 63u) / 64u;
-        const uint32_t lo = tid * per, hi = min(lo + per, nh);
+        const uint32_t lo = lane * per, hi = min(lo + per, nh);
         uint32_t sum = 0;
         for (uint32_t h = lo; h < hi; ++h)
-            sum += hit_pref[h + 1];
+            sum += (hit_cnt[h] + K1_UNIT - 1u) / K1_UNIT;
         uint32_t incl = sum;
 #pragma unroll
         for (uint32_t d = 1; d < 64; d <<= 1) {
             uint32_t o = __shfl_up(incl, d, 64);
-            if (tid >= d)
+            if (lane >= d)
                 incl += o;
         }
         uint32_t run = incl - sum;
-        if (tid == 0)
-            hit_pref[0] = 0;
+        if (lane == 0)
+            hit_upref[0] = 0;
         for (uint32_t h = lo; h < hi; ++h) {
-            run += hit_pref[h + 1];
-            hit_pref[h + 1] = run;
+            run += (hit_cnt[h] + K1_UNIT - 1u) / K1_UNIT;
+            hit_upref[h + 1] = run;
         }
     }
     __syncthreads();
 
-    /* ---- tasks ----------------------------------------------------------- */
-    const uint32_t ntasks = hit_pref[nh];
-    for (uint32_t t = tid; t < ntasks; t += K1_THREADS) {
-        uint32_t lo = 0, hi = nh; /* largest h with hit_pref[h] <= t */
-        while (hi - lo > 1u) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (hit_pref[mid] <= t)
-                lo = mid;
-            else
-                hi = mid;
+    /* ---- units -> survivors ----------------------------------------------- */
+    K1_STAMP(3);
+    const uint32_t nunits = hit_upref[nh];
+    lds_words_t pc = (lds_words_t)progc[wave];
+
+    /* run the n survivors ring[from .. from+n), one per lane of this wave */
+    auto run_survivors = [&](uint32_t from, uint32_t n) {
+        const bool have = lane < n;
+        const uint32_t e = have ? ring[(from + lane) & (K1_RING - 1u)] : 0u;
+        const uint32_t k = e & 0x03FFFFFFu, slot = e >> 26;
+        if (have) {
+            const uint4 *src = (const uint4 *)(T.slot + (size_t)k * MCX_SLOT_WORDS);
+            uint4 v[MCX_SLOT_WORDS / 4];
+#pragma unroll
+            for (uint32_t c = 0; c < MCX_SLOT_WORDS / 4; ++c)
+                v[c] = src[c];
+#pragma unroll
+            for (uint32_t c = 0; c < MCX_SLOT_WORDS / 4; ++c) {
+                progc[wave][(4u * c + 0u) * 64u + lane] = v[c].x;
+                progc[wave][(4u * c + 1u) * 64u + lane] = v[c].y;
+                progc[wave][(4u * c + 2u) * 64u + lane] = v[c].z;
+                progc[wave][(4u * c + 3u) * 64u + lane] = v[c].w;
+            }
         }
-        const uint32_t k = hit_start[lo] + (t - hit_pref[lo]);
-        const uint32_t slot = hit_slot[lo];
-        const uint32_t len = str_len[slot];
-        const uint32_t *prog = T.prog + T.prog_off[k];
-        bool ok;
-        if (use_lds) {
-            LdsStr str{(lds_words_t)str_w, str_at[slot]};
-            ok = mcx_prog_match(prog, str, len, T.sets);
-        } else {
-            GlobalStr str{S + gbase + str_at[slot], len};
-            ok = mcx_prog_match(prog, str, len, T.sets);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        K1_STAMP(7);
+        if (have) {
+            const uint32_t len = str_len[slot];
+            LdsProg lp{pc, lane};
+            const uint32_t hdr = lp[0];
+            const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
+            bool ok;
+            if (use_lds) {
+                LdsStr str{(lds_words_t)str_w, str_at[slot]};
+                if (!is_ext)
+                    ok = mcx_prog_match(lp, 0u, str, len, T.sets);
+                else
+                    ok = mcx_prog_match(GlobalProg{T.ext}, lp[1], str, len, T.sets);
+            } else {
+                GlobalStr str{S + gbase + str_at[slot], len};
+                if (!is_ext)
+                    ok = mcx_prog_match(lp, 0u, str, len, T.sets);
+                else
+                    ok = mcx_prog_match(GlobalProg{T.ext}, lp[1], str, len, T.sets);
+            }
+            if (ok) {
+                atomicMin(&res_first[slot], T.orig[k]);
+                atomicAdd(&res_count[slot], 1u);
+            }
         }
-        if (ok) {
-            atomicMin(&res_first[slot], T.orig[k]);
-            atomicAdd(&res_count[slot], 1u);
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    /* the block walks the units in rounds of K1_WAVES (one unit per wave);
+     * after every round the survivors beyond a multiple of 64 stay in the
+     * ring, the others are run */
+    const uint32_t nrounds = (nunits + K1_WAVES - 1u) / K1_WAVES;
+    uint32_t h = 0;
+    for (uint32_t r = 0; r < nrounds; ++r) {
+        const uint32_t u = r * K1_WAVES + wave;
+        if (u < nunits) {
+            while (hit_upref[h + 1] <= u)
+                ++h;
+            const uint32_t j = u - hit_upref[h];
+            const uint32_t k0 = hit_start[h] + K1_UNIT * j;
+            const uint32_t n = min(K1_UNIT, hit_cnt[h] - K1_UNIT * j);
+            const uint32_t slot = hit_slot[h];
+            k1_sig4_t cur = {{0u, 0u, 0u, 0u}};
+            if (4u * lane + 4u <= n) {
+                cur = *(const k1_sig4_t *)(T.sig + k0 + 4u * lane);
+            } else {
+#pragma unroll
+                for (uint32_t jj = 0; jj < 4; ++jj)
+                    if (4u * lane + jj < n)
+                        cur.v[jj] = T.sig[k0 + 4u * lane + jj];
+            }
+            LdsBloom bl{(lds_words_t)bloom[slot]};
+            bool pass[4];
+            uint32_t npass = 0;
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4; ++jj) {
+                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj], bl);
+                npass += pass[jj] ? 1u : 0u;
+            }
+            /* wave-wide exclusive scan of npass, one reservation per wave */
+            uint32_t incl = npass;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d)
+                    incl += o;
+            }
+            const uint32_t wtotal = __shfl(incl, 63, 64);
+            if (wtotal) {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&ring_tail, wtotal);
+                base = __shfl(base, 0, 64);
+                uint32_t at = base + incl - npass;
+#pragma unroll
+                for (uint32_t jj = 0; jj < 4; ++jj)
+                    if (pass[jj])
+                        ring[(at++) & (K1_RING - 1u)] = (slot << 26) | (k0 + 4u * lane + jj);
+            }
         }
+        __syncthreads();
+        if (dbg_stop != 3) {
+            /* full groups of 64 go now; at most K1_WAVES x 256 new survivors a
+             * round plus 63 left over fit the ring */
+            const uint32_t head = ring_head, avail = ring_tail - head;
+            const uint32_t groups = avail / 64u;
+            for (uint32_t g = wave; g < groups; g += K1_WAVES)
+                run_survivors(head + 64u * g, 64u);
+            __syncthreads();
+            if (tid == 0)
+                ring_head = head + 64u * groups;
+            __syncthreads();
+        }
+    }
+    K1_STAMP(4);
+    if (dbg_stop != 3) {
+        const uint32_t head = ring_head, avail = ring_tail - head; /* < 64 */
+        if (wave == 0 && avail)
+            run_survivors(head, avail);
     }
     __syncthreads();
-    if (tid < nstr) {
-        first_idx[t0 + tid] = res_first[tid];
-        count[t0 + tid] = res_count[tid];
+    K1_STAMP(5);
+    for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
+        first_idx[t0 + i] = res_first[i];
+        count[t0 + i] = res_count[i];
     }
+    K1_STAMP(6);
 }
 
 __global__ void __launch_bounds__(256)
@@ -474,15 +655,17 @@ int mcx_ctx_create(int device_ordinal, void *stream, mcx_ctx **out)
 
 static void free_table(mcx_ctx *ctx)
 {
-    (void)hipFree(ctx->d_prog);
-    (void)hipFree(ctx->d_prog_off);
+    (void)hipFree(ctx->d_slot);
+    (void)hipFree(ctx->d_ext);
+    (void)hipFree(ctx->d_sig);
     (void)hipFree(ctx->d_orig);
     (void)hipFree(ctx->d_slots);
     (void)hipFree(ctx->d_sets);
     (void)hipFree(ctx->d_amod);
     (void)hipFree(ctx->d_hwtag);
-    ctx->d_prog = nullptr;
-    ctx->d_prog_off = nullptr;
+    ctx->d_slot = nullptr;
+    ctx->d_ext = nullptr;
+    ctx->d_sig = nullptr;
     ctx->d_orig = nullptr;
     ctx->d_slots = nullptr;
     ctx->d_sets = nullptr;
@@ -618,8 +801,9 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_table(ctx);
-    if ((rc = dev_upload(ctx, &ctx->d_prog, t.prog.data(), t.prog.size())) != 0 ||
-        (rc = dev_upload(ctx, &ctx->d_prog_off, t.prog_off.data(), t.prog_off.size())) != 0 ||
+    if ((rc = dev_upload(ctx, &ctx->d_slot, t.slot.data(), t.slot.size())) != 0 ||
+        (rc = dev_upload(ctx, &ctx->d_ext, t.ext.data(), t.ext.size())) != 0 ||
+        (rc = dev_upload(ctx, &ctx->d_sig, t.sig.data(), t.sig.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_orig, t.orig.data(), t.orig.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_slots, t.slots.data(), t.slots.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_sets, t.sets.data(), t.sets.size())) != 0 ||
@@ -636,7 +820,7 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     for (uint32_t k = 0; k < ctx->nlens; ++k)
         ctx->lens[k] = t.lens[k];
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
-    ctx->table_bytes = 4 * (uint64_t)(t.prog.size() + t.prog_off.size() + t.orig.size() + t.sets.size()) +
+    ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.orig.size() + t.sets.size()) +
                        sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + 4 * (uint64_t)P + t.hw_tag.size();
     ctx->table_loaded = true;
     return MCX_OK;
@@ -655,20 +839,34 @@ int mcx_alias_table_info(mcx_ctx *ctx, uint32_t *P_out, uint64_t *device_bytes_o
     return MCX_OK;
 }
 
+#ifdef MCX_K1_STAMPS
+static unsigned long long *g_k1_stamps = nullptr;
+static uint32_t g_k1_stamp_blocks = 0;
+/* diagnostic build only: copy out the stamps of the last launch (8 per block) */
+extern "C" int mcx_debug_k1_stamps(unsigned long long *out, uint32_t max_blocks)
+{
+    uint32_t n = g_k1_stamp_blocks < max_blocks ? g_k1_stamp_blocks : max_blocks;
+    if (hipMemcpy(out, g_k1_stamps, 64u * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return (int)n;
+}
+#endif
+
 static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
                               uint32_t *d_first, uint32_t *d_count)
 {
     if (N == 0)
         return MCX_OK;
-    /* few strings: one or two per block so that the whole chip has work;
-     * many strings: 64 per block */
+    /* few strings: one per block, so that the whole chip has work;
+     * many strings: up to 64 per block */
     uint32_t spb = (N + 2047u) / 2048u;
     if (spb > K1_MAX_SPB)
         spb = K1_MAX_SPB;
     uint32_t blocks = (N + spb - 1u) / spb;
     k1_table_t T;
-    T.prog = ctx->d_prog;
-    T.prog_off = ctx->d_prog_off;
+    T.slot = ctx->d_slot;
+    T.ext = ctx->d_ext;
+    T.sig = ctx->d_sig;
     T.orig = ctx->d_orig;
     T.slots = ctx->d_slots;
     T.sets = ctx->d_sets;
@@ -683,9 +881,19 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         str_cap = 1024u;
     if (str_cap > K1_LDS_STR_BYTES)
         str_cap = K1_LDS_STR_BYTES;
-    size_t lds = 4 * ((size_t)str_cap / 4 + 4 + 3 * (size_t)spb * T.nlens + 1);
-    k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, T, d_first,
-                                                               d_count);
+    size_t lds = 4 * ((size_t)str_cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
+    static const uint32_t dbg_stop = getenv("MCX_K1_STOP") ? (uint32_t)atoi(getenv("MCX_K1_STOP")) : 0u;
+    const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
+#ifdef MCX_K1_STAMPS
+    if (!g_k1_stamps)
+        (void)hipMalloc((void **)&g_k1_stamps, 8u * 8u * 65536u);
+    g_k1_stamp_blocks = blocks < 65536u ? blocks : 65536u;
+    k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
+                                                               d_first, d_count, dbg_stop, g_k1_stamps);
+#else
+    k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
+                                                               d_first, d_count, dbg_stop);
+#endif
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
 }

@@ -21,6 +21,18 @@
  *                 nsets words {position in segment (0..15) | set number
  *                 (16..31)}: the byte there must be in that 256-bit set.
  *
+ * Storage: every indexed pattern owns one fixed slot of MCX_SLOT_WORDS words.
+ * A program that fits lives in its slot; a longer one lives in an overflow
+ * array and its slot holds only {header with MCX_PF_EXT set, word offset into
+ * the overflow array}.
+ *
+ * Gram signature: a string that matches a pattern contains every run of
+ * literals of the pattern, hence every 4-byte window ("gram") of such a run.
+ * Each string gets a 256-bit Bloom set of its grams; each pattern names up to
+ * four Bloom bits of its own grams, and is skipped when one of them is missing
+ * from the string's set.  Bit 255 is set for every string (patterns with
+ * fewer than four grams point their spare entries at it).
+ *
  * The same source is compiled for the device (the product path) and for the
  * host, where only the pattern compiler (key hash) and the test suite's CPU
  * twin of the device routine use it.
@@ -36,9 +48,20 @@
 #define MCX_HD static inline
 #endif
 
+#if defined(__clang__)
+#define MCX_UNROLL _Pragma("unroll")
+#else
+#define MCX_UNROLL
+#endif
+
 #define MCX_PF_TRAIL_STAR 1u
 #define MCX_PF_HAS_STAR   2u
 #define MCX_PF_NEVER      4u
+#define MCX_PF_EXT        8u   /* slot holds {header, overflow offset} only */
+
+#define MCX_SLOT_WORDS    32u
+#define MCX_BLOOM_WORDS   8u
+#define MCX_BLOOM_FREE    255u /* the bit every string has */
 
 #define MCX_MAX_PATTERN_BYTES 4096u
 #define MCX_MAX_SEGMENTS      255u
@@ -57,48 +80,67 @@ typedef struct {
     uint32_t count;
 } mcx_slot_t;
 
-/* Hash of a key of `len` bytes: feed the bytes in order, then finish. */
-MCX_HD void mcx_hash_init(uint32_t &a, uint32_t &b)
+/* Hash of a key of `len` <= MCX_KEY_MAX bytes held in little-endian words
+ * kw[0..7] (bytes past `len` must be zero). */
+MCX_HD void mcx_key_hash(const uint32_t *kw, uint32_t len, uint32_t &a, uint32_t &b)
 {
-    a = 0x811C9DC5u;
-    b = 0x9747B28Cu;
-}
-MCX_HD void mcx_hash_byte(uint32_t &a, uint32_t &b, uint32_t byte)
-{
-    a = (a ^ byte) * 0x01000193u;
-    b = (b + byte + 1u) * 0x85EBCA6Bu;
-    b ^= b >> 13;
-}
-MCX_HD void mcx_hash_finish(uint32_t &a, uint32_t &b, uint32_t len)
-{
-    a ^= len * 0x9E3779B1u;
-    a ^= a >> 16;
+    a = 0x811C9DC5u ^ (len * 0x9E3779B1u);
+    b = 0x9747B28Cu + len;
+    MCX_UNROLL
+    for (uint32_t k = 0; k < MCX_KEY_MAX / 4u; ++k) {
+        uint32_t w = (4u * k < len) ? kw[k] : 0u;
+        a = (a ^ w) * 0x01000193u;
+        a ^= a >> 15;
+        b = (b + w) * 0x85EBCA6Bu;
+        b ^= b >> 13;
+    }
     a *= 0x7FEB352Du;
-    a ^= a >> 15;
-    a *= 0x846CA68Bu;
     a ^= a >> 16;
-    b ^= len;
     b *= 0xC2B2AE35u;
     b ^= b >> 16;
+}
+
+/* Bloom bit (0..254) of the gram whose four bytes form the word g */
+MCX_HD uint32_t mcx_gram_bit(uint32_t g)
+{
+    uint32_t h = g * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA6Bu;
+    return (h >> 24) % 255u;
+}
+
+/* does the 256-bit set `bloom` hold the four bits named by `sig`? */
+template <class Bloom>
+MCX_HD bool mcx_sig_pass(uint32_t sig, const Bloom &bloom)
+{
+    /* four independent reads, no early exit */
+    uint32_t all = 1u;
+MCX_UNROLL
+    for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t bit = (sig >> (8u * k)) & 0xFFu;
+        all &= bloom[bit >> 5] >> (bit & 31u);
+    }
+    return (all & 1u) != 0u;
 }
 
 /*
  * Str is any type with
  *   uint32_t word(uint32_t q)  bytes q..q+3 as a little-endian word; bytes at
  *                              or beyond the string's length may hold anything
- *                              (they are always masked), but the read is safe
+ *                              (they are always masked), but reads up to 8
+ *                              bytes past the end are safe
  *   uint32_t byte(uint32_t q)  byte q, q < length
+ * Prog is any type whose operator[](w) returns word w of the program.
  */
-template <class Str>
-MCX_HD bool mcx_seg_rest(const uint32_t *chunks, uint32_t first_chunk, uint32_t nchunks,
-                         const uint32_t *setlist, uint32_t nsets, const Str &s, uint32_t q,
-                         const uint32_t *sets)
+template <class Prog, class Str>
+MCX_HD bool mcx_seg_rest(const Prog &p, uint32_t chunks, uint32_t first_chunk, uint32_t nchunks,
+                         uint32_t setlist, uint32_t nsets, const Str &s, uint32_t q, const uint32_t *sets)
 {
     for (uint32_t c = first_chunk; c < nchunks; ++c)
-        if ((s.word(q + 4u * c) ^ chunks[2u * c]) & chunks[2u * c + 1u])
+        if ((s.word(q + 4u * c) ^ p[chunks + 2u * c]) & p[chunks + 2u * c + 1u])
             return false;
     for (uint32_t k = 0; k < nsets; ++k) {
-        uint32_t e = setlist[k];
+        uint32_t e = p[setlist + k];
         uint32_t ch = s.byte(q + (e & 0xFFFFu));
         if (!((sets[(e >> 16) * 8u + (ch >> 5)] >> (ch & 31u)) & 1u))
             return false;
@@ -106,11 +148,18 @@ MCX_HD bool mcx_seg_rest(const uint32_t *chunks, uint32_t first_chunk, uint32_t 
     return true;
 }
 
-/* Does the compiled pattern at `prog` match the string s[0..len) ? */
-template <class Str>
-MCX_HD bool mcx_prog_match(const uint32_t *prog, const Str &s, uint32_t len, const uint32_t *sets)
+/*
+ * Does the compiled pattern p (header at word `at`) match s[0..len) ?
+ * Every segment is placed the same way: leftmost fit inside a window [lo, hi]
+ * of start positions (a single position for the two anchored kinds), so that
+ * lanes working on different patterns stay in one instruction stream.  When
+ * the segment starts with a literal, the four start positions covered by one
+ * string word are screened at once by a zero-byte test on word ^ literal.
+ */
+template <class Prog, class Str>
+MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, const Str &s, uint32_t len, const uint32_t *sets)
 {
-    const uint32_t hdr = prog[0];
+    const uint32_t hdr = p[at];
     const uint32_t minlen = MCX_HDR_MINLEN(hdr), flags = MCX_HDR_FLAGS(hdr), nseg = MCX_HDR_NSEG(hdr);
     if (flags & MCX_PF_NEVER)
         return false;
@@ -119,45 +168,52 @@ MCX_HD bool mcx_prog_match(const uint32_t *prog, const Str &s, uint32_t len, con
     if (!(flags & MCX_PF_HAS_STAR) && len != minlen)
         return false;
 
-    const uint32_t *p = prog + 1;
+    uint32_t w = at + 1u;
     uint32_t pos = 0;
     for (uint32_t k = 0; k < nseg; ++k) {
-        const uint32_t sh = p[0];
+        const uint32_t sh = p[w];
         const uint32_t nchars = sh & 0xFFFFu, nsets = sh >> 16, nchunks = (nchars + 3u) >> 2;
-        const uint32_t *chunks = p + 1;
-        const uint32_t *setlist = chunks + 2u * nchunks;
-        p = setlist + nsets;
-        if (k == 0) {
-            /* anchored at the start; len >= minlen >= nchars */
-            if (!mcx_seg_rest(chunks, 0u, nchunks, setlist, nsets, s, 0u, sets))
-                return false;
-            pos = nchars;
-        } else if (k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR)) {
-            /* anchored at the end */
-            if (pos + nchars > len)
-                return false;
-            if (!mcx_seg_rest(chunks, 0u, nchunks, setlist, nsets, s, len - nchars, sets))
-                return false;
-            pos = len;
-        } else {
-            /* floating: leftmost fit at or after pos (nchars >= 1 here) */
-            if (pos + nchars > len)
-                return false;
-            const uint32_t last = len - nchars;
-            const uint32_t v0 = chunks[0], m0 = chunks[1];
-            bool found = false;
-            for (uint32_t q = pos; q <= last; ++q) {
-                if ((s.word(q) ^ v0) & m0)
+        const uint32_t chunks = w + 1u;
+        const uint32_t setlist = chunks + 2u * nchunks;
+        w = setlist + nsets;
+        if (nchars == 0u)
+            continue; /* only the anchored first segment can be empty */
+        if (pos + nchars > len)
+            return false;
+        uint32_t lo = pos, hi = len - nchars;
+        if (k == 0u)
+            hi = 0u;
+        else if (k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR))
+            lo = hi;
+        const uint32_t v0 = p[chunks], m0 = p[chunks + 1u];
+        /* first matcher a literal: its byte, repeated, for the screen */
+        const bool lit0 = (m0 & 0xFFu) == 0xFFu;
+        const uint32_t rep = (v0 & 0xFFu) * 0x01010101u;
+        bool found = false;
+        for (uint32_t q = lo; q <= hi && !found; q += 4u) {
+            const uint32_t w0 = s.word(q);
+            uint32_t cand = 0x80808080u; /* bit 8d+7: start position q+d is worth a look */
+            if (lit0) {
+                const uint32_t x = w0 ^ rep;
+                cand = (x - 0x01010101u) & ~x & 0x80808080u;
+            }
+            const uint32_t room = hi - q; /* positions q .. q+min(3,room) exist */
+            if (room < 3u)
+                cand &= 0xFFFFFFFFu >> (8u * (3u - room));
+            while (cand != 0u && !found) {
+                const uint32_t d = (uint32_t)(__builtin_ctz(cand) >> 3);
+                cand &= cand - 1u;
+                const uint32_t win = d ? s.word(q + d) : w0;
+                if ((win ^ v0) & m0)
                     continue;
-                if (mcx_seg_rest(chunks, 1u, nchunks, setlist, nsets, s, q, sets)) {
-                    pos = q + nchars;
+                if (mcx_seg_rest(p, chunks, 1u, nchunks, setlist, nsets, s, q + d, sets)) {
+                    pos = q + d + nchars;
                     found = true;
-                    break;
                 }
             }
-            if (!found)
-                return false;
         }
+        if (!found)
+            return false;
     }
     return true;
 }

@@ -27,6 +27,11 @@ struct HostStr {
     }
 };
 
+struct HostProg {
+    const uint32_t *p;
+    uint32_t operator[](uint32_t w) const { return p[w]; }
+};
+
 static void normalize(std::string &s, bool *bad)
 {
     *bad = false;
@@ -71,7 +76,8 @@ int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t 
     std::vector<uint32_t> prog;
     mcx_emit_program(ir, prog);
     HostStr s{(const uint8_t *)string, sn};
-    return mcx_prog_match(prog.data(), s, sn, t.sets.empty() ? nullptr : t.sets.data()) ? 1 : 0;
+    HostProg hp{prog.data()};
+    return mcx_prog_match(hp, 0u, s, sn, t.sets.empty() ? nullptr : t.sets.data()) ? 1 : 0;
 }
 
 /* Same contract as orc_alias_match; returns 0 or a negative MCX_E_* code.
@@ -97,24 +103,40 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
         if (!bad) {
             uint32_t len = (uint32_t)str.size();
             HostStr s{(const uint8_t *)str.data(), len};
+            /* the string's gram set, as the device builds it */
+            uint32_t bloom[MCX_BLOOM_WORDS] = {0};
+            bloom[MCX_BLOOM_FREE >> 5] |= 1u << (MCX_BLOOM_FREE & 31u);
+            for (uint32_t q = 0; q + 4 <= len; ++q) {
+                uint32_t bit = mcx_gram_bit(s.word(q));
+                bloom[bit >> 5] |= 1u << (bit & 31u);
+            }
             for (uint32_t L : t.lens) {
                 if (L > len)
                     continue;
-                uint32_t a, b;
-                mcx_hash_init(a, b);
+                uint32_t a, b, kw[MCX_KEY_MAX / 4] = {0};
                 for (uint32_t k = 0; k < L; ++k)
-                    mcx_hash_byte(a, b, s.byte(k));
-                mcx_hash_finish(a, b, L);
+                    kw[k >> 2] |= s.byte(k) << (8u * (k & 3u));
+                mcx_key_hash(kw, L, a, b);
                 for (size_t at = a & mask; t.slots[at].count != 0; at = (at + 1) & mask) {
                     const mcx_slot_t &sl = t.slots[at];
                     if (sl.h1 != a || sl.h2 != b)
                         continue;
-                    for (uint32_t k = sl.start; k < sl.start + sl.count; ++k)
-                        if (mcx_prog_match(t.prog.data() + t.prog_off[k], s, len, sets)) {
+                    for (uint32_t k = sl.start; k < sl.start + sl.count; ++k) {
+                        if (!mcx_sig_pass(t.sig[k], bloom))
+                            continue;
+                        const uint32_t *slot = &t.slot[(size_t)k * MCX_SLOT_WORDS];
+                        HostProg hp{slot};
+                        uint32_t at = 0;
+                        if (MCX_HDR_FLAGS(slot[0]) & MCX_PF_EXT) {
+                            hp.p = t.ext.data();
+                            at = slot[1];
+                        }
+                        if (mcx_prog_match(hp, at, s, len, sets)) {
                             if (t.orig[k] < first)
                                 first = t.orig[k];
                             ++cnt;
                         }
+                    }
                     break;
                 }
             }

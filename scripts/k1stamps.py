@@ -1,0 +1,34 @@
+"""Diagnostic: per-phase shader-clock cycles of the K1 kernel (needs `make -C montecarlo_amd/csrc diag`)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MONTECARLO_LIB"] = os.path.join(ROOT, "scripts", "_bin", "libmontecarlo_diag.so")
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from montecarlo_amd import Context, synth, binding  # noqa: E402
+
+N, P = int(os.environ.get("K1_N", 1000)), int(os.environ.get("K1_P", 30000))
+A, a_off, a_mod = synth.alias_table(2, P)
+S, s_off = synth.modalias_strings(2, P, N)
+ctx = Context(0)
+ctx.alias_table_load(A, a_off, a_mod)
+dS, dO = ctx.to_device(S), ctx.to_device(s_off)
+dF, dC = ctx.alloc(4 * N), ctx.alloc(4 * N)
+for _ in range(50):
+    ctx.alias_match_dev(dS.ptr, dO.ptr, N, dF.ptr, dC.ptr)
+ctx.sync()
+lib = binding.load_library()
+buf = np.zeros((65536, 8), dtype=np.uint64)
+n = lib.mcx_debug_k1_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
+st = buf[:n].astype(np.int64)
+d = np.diff(st[:, :7], axis=1)
+names = ["stage", "bloom+probe", "scan", "screen+run", "tail run", "store"]
+print("blocks", n, "kernel span (cycles)", int(st[:, 6].max() - st[:, 0].min()))
+for k, nm in enumerate(names):
+    print("%-12s median %7d  p90 %7d  max %7d" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 90), d[:, k].max()))
+print("tail: fetch   median %7d   interp+orig median %7d" % (np.median(st[:, 7] - st[:, 4]), np.median(st[:, 5] - st[:, 7])))
+print("block total  median %7d  p90 %7d  max %7d" % (np.median(st[:, 6] - st[:, 0]), np.percentile(st[:, 6] - st[:, 0], 90), (st[:, 6] - st[:, 0]).max()))
+print("start skew   median %7d  max %7d" % (np.median(st[:, 0] - st[:, 0].min()), (st[:, 0] - st[:, 0].min()).max()))
