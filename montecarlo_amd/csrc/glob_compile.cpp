@@ -469,6 +469,9 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         }
         out.sig[k] = sig_of(irs[j], keys[j].size());
     }
+    /* the matchers read up to two words past a program: keep them in bounds */
+    out.slot.insert(out.slot.end(), 4, 0u);
+    out.ext.insert(out.ext.end(), 4, 0u);
     /* hash table: at least twice as many slots as groups, never empty */
     size_t cap = 16;
     while (cap < 2 * groups.size())

@@ -88,7 +88,8 @@ static int dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 /* ------------------------------------------------------------------------- */
 
 #define K1_THREADS 256
-#define K1_MAX_SPB 64                       /* strings per block, at most      */
+#define K1_MAX_SPB 16                       /* strings per block, at most      */
+#define K1_OCC_WORDS 512                     /* 256 x 64-bit position sets      */
 #define K1_LDS_STR_BYTES 16384              /* staging buffer for a tile       */
 #define K1_MAX_HITS (K1_MAX_SPB * (MCX_KEY_MAX + 1))
 
@@ -142,11 +143,24 @@ struct GlobalStr {
 struct LdsProg {
     lds_words_t w;
     uint32_t lane;
-    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return w[i * 64u + lane]; }
+    /* in-slot programs end before word 32; the read-ahead of the matchers may
+     * ask for word 32 or 33, which wraps to a word whose value is not used */
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const
+    {
+        return w[(i & (MCX_SLOT_WORDS - 1u)) * 64u + lane];
+    }
 };
 struct GlobalProg {
     const uint32_t *p;
     __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
+};
+/* occurrence table of one string: entry b = 64-bit set of positions holding b */
+struct LdsOcc {
+    lds_words_t w;
+    __device__ __forceinline__ uint64_t operator[](uint32_t b) const
+    {
+        return (uint64_t)w[2u * b] | ((uint64_t)w[2u * b + 1u] << 32);
+    }
 };
 struct LdsBloom {
     lds_words_t w;
@@ -192,14 +206,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 #define K1_STAMP(i)                                                          \
     do {                                                                     \
         if (threadIdx.x == 0)                                                \
-            stamps[blockIdx.x * 8u + (i)] = __builtin_amdgcn_s_memtime();    \
+            stamps[blockIdx.x * 16u + (i)] = __builtin_amdgcn_s_memtime();    \
     } while (0)
 #else
 #define K1_STAMP(i) do { } while (0)
 #endif
     K1_STAMP(0);
     /* dynamic LDS, sized by the launch for its strings-per-block:
-     * [str_cap/4 + 5 words of string bytes][hit_start][hit_slot][hit_cnt][hit_upref + 1] */
+     * [spb occurrence tables][str_cap/4 + 5 words of string bytes][hit_start][hit_slot][hit_cnt][hit_upref + 1] */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
     __shared__ uint32_t progc[K1_WAVES][MCX_SLOT_WORDS * 64];
     __shared__ uint32_t ring[K1_RING];
@@ -208,7 +222,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB];
     __shared__ uint32_t nhits, ring_tail, ring_head;
     const uint32_t max_hits = spb * T.nlens;
-    uint32_t *str_w = k1_lds;
+    uint32_t *occ_w = k1_lds;
+    uint32_t *str_w = occ_w + spb * K1_OCC_WORDS;
     uint32_t *hit_start = str_w + str_cap / 4u + 5u;
     uint32_t *hit_slot = hit_start + max_hits;
     uint32_t *hit_cnt = hit_slot + max_hits;
@@ -248,6 +263,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         ring_tail = 0;
         ring_head = 0;
     }
+    for (uint32_t w = tid; w < nstr * K1_OCC_WORDS; w += K1_THREADS)
+        occ_w[w] = 0u;
     if (use_lds) {
         const uint32_t a0 = gbase - shift; /* arena byte held by buffer byte 0 */
         const uint32_t nwords = (total + shift + 3u) / 4u + 3u;
@@ -278,6 +295,9 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 uint32_t bit = mcx_gram_bit(str.word(q));
                 atomicOr(&bloom[slot][bit >> 5], 1u << (bit & 31u));
             }
+            /* occurrence table, for strings the bit-parallel matcher takes */
+            if (len <= MCX_OCC_MAX_LEN && lane < len)
+                atomicOr(&occ_w[slot * K1_OCC_WORDS + 2u * str.byte(lane) + (lane >> 5)], 1u << (lane & 31u));
         }
     }
 
@@ -382,7 +402,13 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             const uint32_t hdr = lp[0];
             const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
             bool ok;
-            if (use_lds) {
+            if (use_lds && len <= MCX_OCC_MAX_LEN) {
+                LdsOcc occ{(lds_words_t)occ_w + slot * K1_OCC_WORDS};
+                if (!is_ext)
+                    ok = mcx_prog_match_occ(lp, 0u, occ, len, T.sets);
+                else
+                    ok = mcx_prog_match_occ(GlobalProg{T.ext}, lp[1], occ, len, T.sets);
+            } else if (use_lds) {
                 LdsStr str{(lds_words_t)str_w, str_at[slot]};
                 if (!is_ext)
                     ok = mcx_prog_match(lp, 0u, str, len, T.sets);
@@ -395,11 +421,13 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 else
                     ok = mcx_prog_match(GlobalProg{T.ext}, lp[1], str, len, T.sets);
             }
+            K1_STAMP(8);
             if (ok) {
                 atomicMin(&res_first[slot], T.orig[k]);
                 atomicAdd(&res_count[slot], 1u);
             }
         }
+        K1_STAMP(9);
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -471,9 +499,13 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     K1_STAMP(4);
     if (dbg_stop != 3) {
-        const uint32_t head = ring_head, avail = ring_tail - head; /* < 64 */
-        if (wave == 0 && avail)
-            run_survivors(head, avail);
+        /* fewer than 64 are left: split them over the waves, a wave's time
+         * follows its slowest lane, not its lane count */
+        const uint32_t head = ring_head, avail = ring_tail - head;
+        const uint32_t share = (avail + K1_WAVES - 1u) / K1_WAVES;
+        const uint32_t from = wave * share;
+        if (from < avail)
+            run_survivors(head + from, min(share, avail - from));
     }
     __syncthreads();
     K1_STAMP(5);
@@ -846,7 +878,7 @@ static uint32_t g_k1_stamp_blocks = 0;
 extern "C" int mcx_debug_k1_stamps(unsigned long long *out, uint32_t max_blocks)
 {
     uint32_t n = g_k1_stamp_blocks < max_blocks ? g_k1_stamp_blocks : max_blocks;
-    if (hipMemcpy(out, g_k1_stamps, 64u * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy(out, g_k1_stamps, 128u * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
         return -1;
     return (int)n;
 }
@@ -881,12 +913,12 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         str_cap = 1024u;
     if (str_cap > K1_LDS_STR_BYTES)
         str_cap = K1_LDS_STR_BYTES;
-    size_t lds = 4 * ((size_t)str_cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
+    size_t lds = 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)str_cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
     static const uint32_t dbg_stop = getenv("MCX_K1_STOP") ? (uint32_t)atoi(getenv("MCX_K1_STOP")) : 0u;
     const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
 #ifdef MCX_K1_STAMPS
     if (!g_k1_stamps)
-        (void)hipMalloc((void **)&g_k1_stamps, 8u * 8u * 65536u);
+        (void)hipMalloc((void **)&g_k1_stamps, 16u * 8u * 65536u);
     g_k1_stamp_blocks = blocks < 65536u ? blocks : 65536u;
     k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
                                                                d_first, d_count, dbg_stop, g_k1_stamps);

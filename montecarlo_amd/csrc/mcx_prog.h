@@ -218,4 +218,95 @@ MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, const Str &s, uint32_t le
     return true;
 }
 
+/*
+ * The same decision for a string of at most 64 bytes, from its occurrence
+ * table: occ[b] is the 64-bit set of positions q with s[q] == b.  The start
+ * positions at which a segment fits are the AND over its matchers k of
+ * (positions of that matcher's bytes) >> k; placing it is then a bit test
+ * (anchored) or a find-first-set above the previous segment's end (floating).
+ * No loop over string positions, so lanes running different patterns stay
+ * together.
+ */
+#define MCX_OCC_MAX_LEN 64u
+
+template <class Prog, class Occ>
+MCX_HD bool mcx_prog_match_occ(const Prog &p, uint32_t at, const Occ &occ, uint32_t len, const uint32_t *sets)
+{
+    const uint32_t hdr = p[at];
+    const uint32_t minlen = MCX_HDR_MINLEN(hdr), flags = MCX_HDR_FLAGS(hdr), nseg = MCX_HDR_NSEG(hdr);
+    if (flags & MCX_PF_NEVER)
+        return false;
+    if (len < minlen)
+        return false;
+    if (!(flags & MCX_PF_HAS_STAR) && len != minlen)
+        return false;
+    const uint64_t all = len >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << len) - 1u);
+
+    uint32_t w = at + 1u;
+    uint32_t pos = 0;
+    for (uint32_t k = 0; k < nseg; ++k) {
+        const uint32_t sh = p[w];
+        const uint32_t nchars = sh & 0xFFFFu, nsets = sh >> 16, nchunks = (nchars + 3u) >> 2;
+        const uint32_t chunks = w + 1u;
+        const uint32_t setlist = chunks + 2u * nchunks;
+        w = setlist + nsets;
+        if (nchars == 0u)
+            continue; /* only the anchored first segment can be empty */
+        if (pos + nchars > len)
+            return false;
+        /* branch-free and one chunk ahead: the two words of chunk c+1 are
+         * requested before the four table reads of chunk c are combined, and
+         * nothing in the loop body waits on a condition (reads of a program
+         * word or two past the segment, and table entry 0 for padding bytes,
+         * are harmless: their results are masked) */
+        uint64_t M = all;
+        uint32_t v = p[chunks], m = p[chunks + 1u];
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const uint32_t vn = p[chunks + 2u * c + 2u], mn = p[chunks + 2u * c + 3u];
+            const uint64_t o0 = occ[v & 0xFFu], o1 = occ[(v >> 8) & 0xFFu];
+            const uint64_t o2 = occ[(v >> 16) & 0xFFu], o3 = occ[v >> 24];
+            const uint32_t k0 = 4u * c;
+            const uint32_t left = nchars - k0; /* matchers in this chunk and after */
+            const uint64_t c0 = (m & 0xFFu) ? o0 : all;
+            const uint64_t c1 = (m & 0xFF00u) ? o1 : all;
+            const uint64_t c2 = (m & 0xFF0000u) ? o2 : all;
+            const uint64_t c3 = (m & 0xFF000000u) ? o3 : all;
+            const uint64_t keep = ~(uint64_t)0;
+            M &= c0 >> k0; /* left >= 1 always */
+            M &= (left > 1u) ? (c1 >> ((k0 + 1u) & 63u)) : keep;
+            M &= (left > 2u) ? (c2 >> ((k0 + 2u) & 63u)) : keep;
+            M &= (left > 3u) ? (c3 >> ((k0 + 3u) & 63u)) : keep;
+            v = vn;
+            m = mn;
+        }
+        for (uint32_t e = 0; e < nsets; ++e) {
+            const uint32_t ent = p[setlist + e];
+            uint64_t cls = 0;
+            for (uint32_t wi = 0; wi < 8u; ++wi) {
+                uint32_t bits = sets[(ent >> 16) * 8u + wi];
+                while (bits) {
+                    cls |= occ[wi * 32u + (uint32_t)__builtin_ctz(bits)];
+                    bits &= bits - 1u;
+                }
+            }
+            M &= cls >> (ent & 0xFFFFu);
+        }
+        if (k == 0u) {
+            if (!(M & 1u))
+                return false;
+            pos = nchars;
+        } else if (k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR)) {
+            if (!((M >> (len - nchars)) & 1u))
+                return false;
+            pos = len;
+        } else {
+            M &= ~(uint64_t)0 << pos;
+            if (M == 0u)
+                return false;
+            pos = (uint32_t)__builtin_ctzll(M) + nchars;
+        }
+    }
+    return true;
+}
+
 #endif /* MCX_PROG_H */

@@ -32,6 +32,26 @@ struct HostProg {
     uint32_t operator[](uint32_t w) const { return p[w]; }
 };
 
+struct HostOcc {
+    uint64_t t[256];
+    uint64_t operator[](uint32_t b) const { return t[b]; }
+};
+
+/* the device's choice: occurrence-table matcher for strings of up to 64
+ * bytes, position-loop matcher for longer ones */
+static bool match_like_device(const HostProg &hp, uint32_t at, const HostStr &s, uint32_t len,
+                              const uint32_t *sets)
+{
+    if (len > MCX_OCC_MAX_LEN)
+        return mcx_prog_match(hp, at, s, len, sets);
+    HostOcc occ;
+    memset(&occ, 0, sizeof occ);
+    for (uint32_t q = 0; q < len; ++q)
+        occ.t[s.byte(q)] |= (uint64_t)1 << q;
+    bool a = mcx_prog_match_occ(hp, at, occ, len, sets);
+    return a;
+}
+
 static void normalize(std::string &s, bool *bad)
 {
     *bad = false;
@@ -75,9 +95,14 @@ int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t 
         return rc;
     std::vector<uint32_t> prog;
     mcx_emit_program(ir, prog);
+    prog.insert(prog.end(), 4, 0u); /* read-ahead room */
     HostStr s{(const uint8_t *)string, sn};
     HostProg hp{prog.data()};
-    return mcx_prog_match(hp, 0u, s, sn, t.sets.empty() ? nullptr : t.sets.data()) ? 1 : 0;
+    const uint32_t *sets = t.sets.empty() ? nullptr : t.sets.data();
+    int r = mcx_prog_match(hp, 0u, s, sn, sets) ? 1 : 0;
+    if (sn <= MCX_OCC_MAX_LEN && (match_like_device(hp, 0u, s, sn, sets) ? 1 : 0) != r)
+        return -100; /* the two matchers disagree */
+    return r;
 }
 
 /* Same contract as orc_alias_match; returns 0 or a negative MCX_E_* code.
@@ -131,7 +156,7 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
                             hp.p = t.ext.data();
                             at = slot[1];
                         }
-                        if (mcx_prog_match(hp, at, s, len, sets)) {
+                        if (match_like_device(hp, at, s, len, sets)) {
                             if (t.orig[k] < first)
                                 first = t.orig[k];
                             ++cnt;

@@ -21,7 +21,7 @@ for _ in range(50):
     ctx.alias_match_dev(dS.ptr, dO.ptr, N, dF.ptr, dC.ptr)
 ctx.sync()
 lib = binding.load_library()
-buf = np.zeros((65536, 8), dtype=np.uint64)
+buf = np.zeros((65536, 16), dtype=np.uint64)
 n = lib.mcx_debug_k1_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
 st = buf[:n].astype(np.int64)
 d = np.diff(st[:, :7], axis=1)
@@ -30,5 +30,6 @@ print("blocks", n, "kernel span (cycles)", int(st[:, 6].max() - st[:, 0].min()))
 for k, nm in enumerate(names):
     print("%-12s median %7d  p90 %7d  max %7d" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 90), d[:, k].max()))
 print("tail: fetch   median %7d   interp+orig median %7d" % (np.median(st[:, 7] - st[:, 4]), np.median(st[:, 5] - st[:, 7])))
+print("tail wave0: match median %7d  orig+atomics median %7d  wait others %7d" % (np.median(st[:, 8] - st[:, 7]), np.median(st[:, 9] - st[:, 8]), np.median(st[:, 5] - st[:, 9])))
 print("block total  median %7d  p90 %7d  max %7d" % (np.median(st[:, 6] - st[:, 0]), np.percentile(st[:, 6] - st[:, 0], 90), (st[:, 6] - st[:, 0]).max()))
 print("start skew   median %7d  max %7d" % (np.median(st[:, 0] - st[:, 0].min()), (st[:, 0] - st[:, 0].min()).max()))
