@@ -327,9 +327,9 @@ int mcx_parse_pattern(const uint8_t *pat_in, size_t n, bool normalize_dash, mcx_
     return 0;
 }
 
-void mcx_emit_program(const mcx_pattern_ir &ir, std::vector<uint32_t> &prog)
+void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, std::vector<uint32_t> &prog)
 {
-    prog.push_back(MCX_HDR(ir.minlen, ir.flags, ir.segs.size()));
+    prog.push_back(MCX_HDR(ir.minlen, ir.flags, keylen, ir.segs.size()));
     for (const auto &sg : ir.segs) {
         uint32_t nchars = (uint32_t)sg.size(), nchunks = (nchars + 3u) / 4u;
         std::vector<uint32_t> setlist;
@@ -441,9 +441,8 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         return x < y;
     });
     size_t n_idx = order.size();
-    out.orig.assign(order.begin(), order.end());
     out.slot.assign(n_idx * (size_t)MCX_SLOT_WORDS, 0u);
-    out.sig.resize(n_idx);
+    out.sigorig.resize(2 * n_idx);
     std::vector<uint32_t> one;
     struct Group {
         uint32_t start, count;
@@ -458,16 +457,17 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         }
         groups.back().count++;
         one.clear();
-        mcx_emit_program(irs[j], one);
+        mcx_emit_program(irs[j], (uint32_t)keys[j].size(), one);
         uint32_t *sl = &out.slot[k * (size_t)MCX_SLOT_WORDS];
         if (one.size() <= MCX_SLOT_WORDS) {
             std::copy(one.begin(), one.end(), sl);
         } else {
-            sl[0] = MCX_HDR(irs[j].minlen, irs[j].flags | MCX_PF_EXT, irs[j].segs.size());
+            sl[0] = MCX_HDR(irs[j].minlen, irs[j].flags | MCX_PF_EXT, keys[j].size(), irs[j].segs.size());
             sl[1] = (uint32_t)out.ext.size();
             out.ext.insert(out.ext.end(), one.begin(), one.end());
         }
-        out.sig[k] = sig_of(irs[j], keys[j].size());
+        out.sigorig[2 * k] = sig_of(irs[j], keys[j].size());
+        out.sigorig[2 * k + 1] = j;
     }
     /* the matchers read up to two words past a program: keep them in bounds */
     out.slot.insert(out.slot.end(), 4, 0u);
@@ -476,23 +476,18 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     size_t cap = 16;
     while (cap < 2 * groups.size())
         cap *= 2;
-    out.slots.assign(cap, mcx_slot_t{0, 0, 0, 0});
+    out.slots.assign(cap, mcx_slot_t{0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}});
     for (const Group &g : groups) {
         const std::string &key = keys[order[g.start]];
         uint32_t a, b, kw[MCX_KEY_MAX / 4] = {0};
         memcpy(kw, key.data(), key.size());
         mcx_key_hash(kw, (uint32_t)key.size(), a, b);
         size_t at = a & (cap - 1);
-        while (out.slots[at].count != 0) {
-            if (out.slots[at].h1 == a && out.slots[at].h2 == b) {
-                /* two different keys with one 64-bit hash: a probe would see
-                 * only the first group, so refuse rather than miss matches */
-                err = "prefix-index hash collision";
-                return MCX_E_PATTERN;
-            }
+        while (out.slots[at].count != 0)
             at = (at + 1) & (cap - 1);
-        }
-        out.slots[at] = mcx_slot_t{a, b, g.start, g.count};
+        mcx_slot_t sl = mcx_slot_t{a, b, g.start, g.count, {0, 0, 0, 0, 0, 0, 0, 0}};
+        memcpy(sl.key, kw, sizeof kw);
+        out.slots[at] = sl;
     }
     return 0;
 }

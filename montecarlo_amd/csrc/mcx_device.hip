@@ -37,8 +37,7 @@ struct mcx_ctx {
     uint32_t n_indexed = 0;          /* patterns that can match anything       */
     uint32_t *d_slot = nullptr;      /* n_indexed program slots, index order   */
     uint32_t *d_ext = nullptr;       /* overflow programs                      */
-    uint32_t *d_sig = nullptr;       /* n_indexed gram signatures              */
-    uint32_t *d_orig = nullptr;      /* n_indexed table positions              */
+    uint32_t *d_sigorig = nullptr;   /* n_indexed x {gram signature, position} */
     mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
     uint32_t slot_mask = 0;
     uint32_t nlens = 0;
@@ -98,8 +97,7 @@ static int dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 struct k1_table_t {
     const uint32_t *slot;   /* n_indexed x MCX_SLOT_WORDS                       */
     const uint32_t *ext;    /* overflow programs                               */
-    const uint32_t *sig;    /* n_indexed gram signatures                       */
-    const uint32_t *orig;   /* n_indexed table positions                       */
+    const uint2 *sigorig;   /* n_indexed x {gram signature, table position}    */
     const mcx_slot_t *slots;
     const uint32_t *sets;
     uint32_t slot_mask;
@@ -138,18 +136,6 @@ struct GlobalStr {
     }
 };
 
-/* a lane's program slot, copied to LDS as [word][lane] so that 64 lanes
- * reading the same word index hit 64 different banks */
-struct LdsProg {
-    lds_words_t w;
-    uint32_t lane;
-    /* in-slot programs end before word 32; the read-ahead of the matchers may
-     * ask for word 32 or 33, which wraps to a word whose value is not used */
-    __device__ __forceinline__ uint32_t operator[](uint32_t i) const
-    {
-        return w[(i & (MCX_SLOT_WORDS - 1u)) * 64u + lane];
-    }
-};
 struct GlobalProg {
     const uint32_t *p;
     __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
@@ -171,8 +157,8 @@ struct LdsBloom {
 #define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
 #define K1_WAVES (K1_THREADS / 64)
 
-struct __attribute__((aligned(4))) k1_sig4_t {
-    uint32_t v[4];
+struct __attribute__((aligned(8))) k1_sig4_t {
+    uint2 v[4]; /* {signature, table position} of four consecutive patterns */
 };
 
 /*
@@ -195,7 +181,7 @@ struct __attribute__((aligned(4))) k1_sig4_t {
 __global__ void __launch_bounds__(K1_THREADS)
 k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
                  uint32_t str_cap, uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
-                 uint32_t *__restrict__ count, uint32_t dbg_stop
+                 uint32_t *__restrict__ count
 #ifdef MCX_K1_STAMPS
                  , unsigned long long *__restrict__ stamps
 #endif
@@ -215,8 +201,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     /* dynamic LDS, sized by the launch for its strings-per-block:
      * [spb occurrence tables][str_cap/4 + 5 words of string bytes][hit_start][hit_slot][hit_cnt][hit_upref + 1] */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
-    __shared__ uint32_t progc[K1_WAVES][MCX_SLOT_WORDS * 64];
-    __shared__ uint32_t ring[K1_RING];
+    __shared__ uint32_t ring[K1_RING], ring_orig[K1_RING];
     __shared__ uint32_t bloom[K1_MAX_SPB][MCX_BLOOM_WORDS];
     __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
     __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB];
@@ -284,7 +269,6 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     __syncthreads();
     K1_STAMP(1);
-    if (dbg_stop == 1) return;
 
     /* ---- gram sets: one wave per string, one lane per start position ------- */
     if (use_lds) {
@@ -331,7 +315,11 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             const mcx_slot_t sl = T.slots[at];
             if (sl.count == 0u)
                 break;
-            if (sl.h1 == a && sl.h2 == b) {
+            bool same = sl.h1 == a && sl.h2 == b;
+#pragma unroll
+            for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                same = same && sl.key[k] == kw[k];
+            if (same) {
                 uint32_t h = atomicAdd(&nhits, 1u);
                 hit_start[h] = sl.start;
                 hit_slot[h] = slot;
@@ -342,7 +330,6 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     __syncthreads();
     K1_STAMP(2);
-    if (dbg_stop == 2) return;
 
     /* ---- exclusive prefix sum of the hits' unit counts (first wave) ------- */
     const uint32_t nh = nhits;
@@ -372,58 +359,38 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     /* ---- units -> survivors ----------------------------------------------- */
     K1_STAMP(3);
     const uint32_t nunits = hit_upref[nh];
-    lds_words_t pc = (lds_words_t)progc[wave];
 
     /* run the n survivors ring[from .. from+n), one per lane of this wave */
     auto run_survivors = [&](uint32_t from, uint32_t n) {
         const bool have = lane < n;
         const uint32_t e = have ? ring[(from + lane) & (K1_RING - 1u)] : 0u;
+        const uint32_t orig = have ? ring_orig[(from + lane) & (K1_RING - 1u)] : 0u;
         const uint32_t k = e & 0x03FFFFFFu, slot = e >> 26;
-        if (have) {
-            const uint4 *src = (const uint4 *)(T.slot + (size_t)k * MCX_SLOT_WORDS);
-            uint4 v[MCX_SLOT_WORDS / 4];
-#pragma unroll
-            for (uint32_t c = 0; c < MCX_SLOT_WORDS / 4; ++c)
-                v[c] = src[c];
-#pragma unroll
-            for (uint32_t c = 0; c < MCX_SLOT_WORDS / 4; ++c) {
-                progc[wave][(4u * c + 0u) * 64u + lane] = v[c].x;
-                progc[wave][(4u * c + 1u) * 64u + lane] = v[c].y;
-                progc[wave][(4u * c + 2u) * 64u + lane] = v[c].z;
-                progc[wave][(4u * c + 3u) * 64u + lane] = v[c].w;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
         K1_STAMP(7);
         if (have) {
+            /* the program is read in place: its slot is one 128-byte line */
             const uint32_t len = str_len[slot];
-            LdsProg lp{pc, lane};
+            const GlobalProg lp{T.slot + (size_t)k * MCX_SLOT_WORDS};
             const uint32_t hdr = lp[0];
             const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
+            const GlobalProg gp{is_ext ? T.ext : lp.p};
+            const uint32_t at = is_ext ? lp[1] : 0u;
             bool ok;
             if (use_lds && len <= MCX_OCC_MAX_LEN) {
+                /* the probe compared the key's bytes: skip them */
                 LdsOcc occ{(lds_words_t)occ_w + slot * K1_OCC_WORDS};
-                if (!is_ext)
-                    ok = mcx_prog_match_occ(lp, 0u, occ, len, T.sets);
-                else
-                    ok = mcx_prog_match_occ(GlobalProg{T.ext}, lp[1], occ, len, T.sets);
+                LdsStr str{(lds_words_t)str_w, str_at[slot]};
+                ok = mcx_prog_match_occ(gp, at, str, occ, len, MCX_HDR_KEYLEN(hdr), T.sets);
             } else if (use_lds) {
                 LdsStr str{(lds_words_t)str_w, str_at[slot]};
-                if (!is_ext)
-                    ok = mcx_prog_match(lp, 0u, str, len, T.sets);
-                else
-                    ok = mcx_prog_match(GlobalProg{T.ext}, lp[1], str, len, T.sets);
+                ok = mcx_prog_match(gp, at, str, len, T.sets);
             } else {
                 GlobalStr str{S + gbase + str_at[slot], len};
-                if (!is_ext)
-                    ok = mcx_prog_match(lp, 0u, str, len, T.sets);
-                else
-                    ok = mcx_prog_match(GlobalProg{T.ext}, lp[1], str, len, T.sets);
+                ok = mcx_prog_match(gp, at, str, len, T.sets);
             }
             K1_STAMP(8);
             if (ok) {
-                atomicMin(&res_first[slot], T.orig[k]);
+                atomicMin(&res_first[slot], orig);
                 atomicAdd(&res_count[slot], 1u);
             }
         }
@@ -445,21 +412,24 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             const uint32_t k0 = hit_start[h] + K1_UNIT * j;
             const uint32_t n = min(K1_UNIT, hit_cnt[h] - K1_UNIT * j);
             const uint32_t slot = hit_slot[h];
-            k1_sig4_t cur = {{0u, 0u, 0u, 0u}};
+            k1_sig4_t cur;
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4; ++jj)
+                cur.v[jj] = make_uint2(0u, 0u);
             if (4u * lane + 4u <= n) {
-                cur = *(const k1_sig4_t *)(T.sig + k0 + 4u * lane);
+                cur = *(const k1_sig4_t *)(T.sigorig + k0 + 4u * lane);
             } else {
 #pragma unroll
                 for (uint32_t jj = 0; jj < 4; ++jj)
                     if (4u * lane + jj < n)
-                        cur.v[jj] = T.sig[k0 + 4u * lane + jj];
+                        cur.v[jj] = T.sigorig[k0 + 4u * lane + jj];
             }
             LdsBloom bl{(lds_words_t)bloom[slot]};
             bool pass[4];
             uint32_t npass = 0;
 #pragma unroll
             for (uint32_t jj = 0; jj < 4; ++jj) {
-                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj], bl);
+                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj].x, bl);
                 npass += pass[jj] ? 1u : 0u;
             }
             /* wave-wide exclusive scan of npass, one reservation per wave */
@@ -479,12 +449,15 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 uint32_t at = base + incl - npass;
 #pragma unroll
                 for (uint32_t jj = 0; jj < 4; ++jj)
-                    if (pass[jj])
-                        ring[(at++) & (K1_RING - 1u)] = (slot << 26) | (k0 + 4u * lane + jj);
+                    if (pass[jj]) {
+                        ring[at & (K1_RING - 1u)] = (slot << 26) | (k0 + 4u * lane + jj);
+                        ring_orig[at & (K1_RING - 1u)] = cur.v[jj].y;
+                        ++at;
+                    }
             }
         }
         __syncthreads();
-        if (dbg_stop != 3) {
+        {
             /* full groups of 64 go now; at most K1_WAVES x 256 new survivors a
              * round plus 63 left over fit the ring */
             const uint32_t head = ring_head, avail = ring_tail - head;
@@ -498,7 +471,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         }
     }
     K1_STAMP(4);
-    if (dbg_stop != 3) {
+    {
         /* fewer than 64 are left: split them over the waves, a wave's time
          * follows its slowest lane, not its lane count */
         const uint32_t head = ring_head, avail = ring_tail - head;
@@ -689,16 +662,14 @@ static void free_table(mcx_ctx *ctx)
 {
     (void)hipFree(ctx->d_slot);
     (void)hipFree(ctx->d_ext);
-    (void)hipFree(ctx->d_sig);
-    (void)hipFree(ctx->d_orig);
+    (void)hipFree(ctx->d_sigorig);
     (void)hipFree(ctx->d_slots);
     (void)hipFree(ctx->d_sets);
     (void)hipFree(ctx->d_amod);
     (void)hipFree(ctx->d_hwtag);
     ctx->d_slot = nullptr;
     ctx->d_ext = nullptr;
-    ctx->d_sig = nullptr;
-    ctx->d_orig = nullptr;
+    ctx->d_sigorig = nullptr;
     ctx->d_slots = nullptr;
     ctx->d_sets = nullptr;
     ctx->d_amod = nullptr;
@@ -835,8 +806,7 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     free_table(ctx);
     if ((rc = dev_upload(ctx, &ctx->d_slot, t.slot.data(), t.slot.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_ext, t.ext.data(), t.ext.size())) != 0 ||
-        (rc = dev_upload(ctx, &ctx->d_sig, t.sig.data(), t.sig.size())) != 0 ||
-        (rc = dev_upload(ctx, &ctx->d_orig, t.orig.data(), t.orig.size())) != 0 ||
+        (rc = dev_upload(ctx, &ctx->d_sigorig, t.sigorig.data(), t.sigorig.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_slots, t.slots.data(), t.slots.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_sets, t.sets.data(), t.sets.size())) != 0 ||
         (rc = dev_upload(ctx, &ctx->d_amod, a_mod, (size_t)P)) != 0 ||
@@ -846,13 +816,13 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->P = P;
-    ctx->n_indexed = (uint32_t)t.orig.size();
+    ctx->n_indexed = (uint32_t)(t.sigorig.size() / 2);
     ctx->slot_mask = (uint32_t)t.slots.size() - 1u;
     ctx->nlens = (uint32_t)t.lens.size();
     for (uint32_t k = 0; k < ctx->nlens; ++k)
         ctx->lens[k] = t.lens[k];
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
-    ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.orig.size() + t.sets.size()) +
+    ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sigorig.size() + t.sets.size()) +
                        sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + 4 * (uint64_t)P + t.hw_tag.size();
     ctx->table_loaded = true;
     return MCX_OK;
@@ -898,8 +868,7 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     k1_table_t T;
     T.slot = ctx->d_slot;
     T.ext = ctx->d_ext;
-    T.sig = ctx->d_sig;
-    T.orig = ctx->d_orig;
+    T.sigorig = (const uint2 *)ctx->d_sigorig;
     T.slots = ctx->d_slots;
     T.sets = ctx->d_sets;
     T.slot_mask = ctx->slot_mask;
@@ -914,17 +883,16 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     if (str_cap > K1_LDS_STR_BYTES)
         str_cap = K1_LDS_STR_BYTES;
     size_t lds = 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)str_cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
-    static const uint32_t dbg_stop = getenv("MCX_K1_STOP") ? (uint32_t)atoi(getenv("MCX_K1_STOP")) : 0u;
     const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
 #ifdef MCX_K1_STAMPS
     if (!g_k1_stamps)
         (void)hipMalloc((void **)&g_k1_stamps, 16u * 8u * 65536u);
     g_k1_stamp_blocks = blocks < 65536u ? blocks : 65536u;
     k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
-                                                               d_first, d_count, dbg_stop, g_k1_stamps);
+                                                               d_first, d_count, g_k1_stamps);
 #else
     k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
-                                                               d_first, d_count, dbg_stop);
+                                                               d_first, d_count);
 #endif
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;

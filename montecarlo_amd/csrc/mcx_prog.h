@@ -11,7 +11,7 @@
  * (posix/fnmatch_loop.c, the '*' case), without its recursion.
  *
  * Encoding, 32-bit words:
- *   word 0        minlen (bits 0..15) | flags (16..23) | nseg (24..31)
+ *   word 0        minlen | flags | keylen | nseg (MCX_HDR)
  *   per segment   header: nchars (0..15) | nsets (16..31)
  *                 ceil(nchars/4) chunks of two words {value, mask}: string
  *                 bytes q+4c .. q+4c+3, read as one little-endian word w,
@@ -67,9 +67,15 @@
 #define MCX_MAX_SEGMENTS      255u
 #define MCX_KEY_MAX           32u   /* longest literal prefix used as index key */
 
-#define MCX_HDR(minlen, flags, nseg) ((uint32_t)(minlen) | ((uint32_t)(flags) << 16) | ((uint32_t)(nseg) << 24))
-#define MCX_HDR_MINLEN(w) ((w) & 0xFFFFu)
-#define MCX_HDR_FLAGS(w) (((w) >> 16) & 0xFFu)
+/* header word: minlen 0..12, flags 13..16, keylen 17..22, nseg 24..31.  keylen
+ * = number of leading literals of the first segment that the index key of the
+ * pattern's group covers (a string reaches the pattern only after those bytes
+ * have been compared). */
+#define MCX_HDR(minlen, flags, keylen, nseg) \
+    ((uint32_t)(minlen) | ((uint32_t)(flags) << 13) | ((uint32_t)(keylen) << 17) | ((uint32_t)(nseg) << 24))
+#define MCX_HDR_MINLEN(w) ((w) & 0x1FFFu)
+#define MCX_HDR_FLAGS(w) (((w) >> 13) & 0xFu)
+#define MCX_HDR_KEYLEN(w) (((w) >> 17) & 0x3Fu)
 #define MCX_HDR_NSEG(w) ((w) >> 24)
 
 /* one slot of the prefix index: a group of patterns that share the literal
@@ -78,6 +84,7 @@ typedef struct {
     uint32_t h1, h2;
     uint32_t start; /* first pattern of the group, in index order */
     uint32_t count;
+    uint32_t key[8]; /* the literal prefix itself, zero padded */
 } mcx_slot_t;
 
 /* Hash of a key of `len` <= MCX_KEY_MAX bytes held in little-endian words
@@ -219,18 +226,64 @@ MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, const Str &s, uint32_t le
 }
 
 /*
- * The same decision for a string of at most 64 bytes, from its occurrence
- * table: occ[b] is the 64-bit set of positions q with s[q] == b.  The start
- * positions at which a segment fits are the AND over its matchers k of
- * (positions of that matcher's bytes) >> k; placing it is then a bit test
- * (anchored) or a find-first-set above the previous segment's end (floating).
- * No loop over string positions, so lanes running different patterns stay
- * together.
+ * The same decision for a string of at most 64 bytes, with its occurrence
+ * table: occ[b] is the 64-bit set of positions q with s[q] == b.  Anchored
+ * segments are compared word by word at their one position (the first one
+ * from `skip` bytes on: the caller has already compared those).  For a
+ * floating segment the start positions at which it fits are the AND over its
+ * matchers k of (positions of that matcher's bytes) >> k, and placing it is a
+ * find-first-set above the previous segment's end: no loop over string
+ * positions, so lanes running different patterns stay together.
  */
 #define MCX_OCC_MAX_LEN 64u
 
 template <class Prog, class Occ>
-MCX_HD bool mcx_prog_match_occ(const Prog &p, uint32_t at, const Occ &occ, uint32_t len, const uint32_t *sets)
+MCX_HD uint64_t mcx_seg_fits(const Prog &p, uint32_t chunks, uint32_t nchars, uint32_t setlist, uint32_t nsets,
+                             const Occ &occ, uint64_t all, const uint32_t *sets)
+{
+    /* branch-free and one chunk ahead: the two words of chunk c+1 are requested
+     * before the four table reads of chunk c are combined (reads of a program
+     * word or two past the segment, and of table entry 0 for padding bytes, are
+     * harmless: their results are masked) */
+    const uint32_t nchunks = (nchars + 3u) >> 2;
+    uint64_t M = all;
+    uint32_t v = p[chunks], m = p[chunks + 1u];
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t vn = p[chunks + 2u * c + 2u], mn = p[chunks + 2u * c + 3u];
+        const uint64_t o0 = occ[v & 0xFFu], o1 = occ[(v >> 8) & 0xFFu];
+        const uint64_t o2 = occ[(v >> 16) & 0xFFu], o3 = occ[v >> 24];
+        const uint32_t k0 = 4u * c;
+        const uint32_t left = nchars - k0; /* matchers in this chunk and after */
+        const uint64_t c0 = (m & 0xFFu) ? o0 : all;
+        const uint64_t c1 = (m & 0xFF00u) ? o1 : all;
+        const uint64_t c2 = (m & 0xFF0000u) ? o2 : all;
+        const uint64_t c3 = (m & 0xFF000000u) ? o3 : all;
+        const uint64_t keep = ~(uint64_t)0;
+        M &= c0 >> k0; /* left >= 1 always */
+        M &= (left > 1u) ? (c1 >> ((k0 + 1u) & 63u)) : keep;
+        M &= (left > 2u) ? (c2 >> ((k0 + 2u) & 63u)) : keep;
+        M &= (left > 3u) ? (c3 >> ((k0 + 3u) & 63u)) : keep;
+        v = vn;
+        m = mn;
+    }
+    for (uint32_t e = 0; e < nsets; ++e) {
+        const uint32_t ent = p[setlist + e];
+        uint64_t cls = 0;
+        for (uint32_t wi = 0; wi < 8u; ++wi) {
+            uint32_t bits = sets[(ent >> 16) * 8u + wi];
+            while (bits) {
+                cls |= occ[wi * 32u + (uint32_t)__builtin_ctz(bits)];
+                bits &= bits - 1u;
+            }
+        }
+        M &= cls >> (ent & 0xFFFFu);
+    }
+    return M;
+}
+
+template <class Prog, class Str, class Occ>
+MCX_HD bool mcx_prog_match_occ(const Prog &p, uint32_t at, const Str &s, const Occ &occ, uint32_t len,
+                               uint32_t skip, const uint32_t *sets)
 {
     const uint32_t hdr = p[at];
     const uint32_t minlen = MCX_HDR_MINLEN(hdr), flags = MCX_HDR_FLAGS(hdr), nseg = MCX_HDR_NSEG(hdr);
@@ -254,52 +307,16 @@ MCX_HD bool mcx_prog_match_occ(const Prog &p, uint32_t at, const Occ &occ, uint3
             continue; /* only the anchored first segment can be empty */
         if (pos + nchars > len)
             return false;
-        /* branch-free and one chunk ahead: the two words of chunk c+1 are
-         * requested before the four table reads of chunk c are combined, and
-         * nothing in the loop body waits on a condition (reads of a program
-         * word or two past the segment, and table entry 0 for padding bytes,
-         * are harmless: their results are masked) */
-        uint64_t M = all;
-        uint32_t v = p[chunks], m = p[chunks + 1u];
-        for (uint32_t c = 0; c < nchunks; ++c) {
-            const uint32_t vn = p[chunks + 2u * c + 2u], mn = p[chunks + 2u * c + 3u];
-            const uint64_t o0 = occ[v & 0xFFu], o1 = occ[(v >> 8) & 0xFFu];
-            const uint64_t o2 = occ[(v >> 16) & 0xFFu], o3 = occ[v >> 24];
-            const uint32_t k0 = 4u * c;
-            const uint32_t left = nchars - k0; /* matchers in this chunk and after */
-            const uint64_t c0 = (m & 0xFFu) ? o0 : all;
-            const uint64_t c1 = (m & 0xFF00u) ? o1 : all;
-            const uint64_t c2 = (m & 0xFF0000u) ? o2 : all;
-            const uint64_t c3 = (m & 0xFF000000u) ? o3 : all;
-            const uint64_t keep = ~(uint64_t)0;
-            M &= c0 >> k0; /* left >= 1 always */
-            M &= (left > 1u) ? (c1 >> ((k0 + 1u) & 63u)) : keep;
-            M &= (left > 2u) ? (c2 >> ((k0 + 2u) & 63u)) : keep;
-            M &= (left > 3u) ? (c3 >> ((k0 + 3u) & 63u)) : keep;
-            v = vn;
-            m = mn;
-        }
-        for (uint32_t e = 0; e < nsets; ++e) {
-            const uint32_t ent = p[setlist + e];
-            uint64_t cls = 0;
-            for (uint32_t wi = 0; wi < 8u; ++wi) {
-                uint32_t bits = sets[(ent >> 16) * 8u + wi];
-                while (bits) {
-                    cls |= occ[wi * 32u + (uint32_t)__builtin_ctz(bits)];
-                    bits &= bits - 1u;
-                }
-            }
-            M &= cls >> (ent & 0xFFFFu);
-        }
         if (k == 0u) {
-            if (!(M & 1u))
+            if (!mcx_seg_rest(p, chunks, skip >> 2, nchunks, setlist, nsets, s, 0u, sets))
                 return false;
             pos = nchars;
         } else if (k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR)) {
-            if (!((M >> (len - nchars)) & 1u))
+            if (!mcx_seg_rest(p, chunks, 0u, nchunks, setlist, nsets, s, len - nchars, sets))
                 return false;
             pos = len;
         } else {
+            uint64_t M = mcx_seg_fits(p, chunks, nchars, setlist, nsets, occ, all, sets);
             M &= ~(uint64_t)0 << pos;
             if (M == 0u)
                 return false;

@@ -40,7 +40,7 @@ struct HostOcc {
 /* the device's choice: occurrence-table matcher for strings of up to 64
  * bytes, position-loop matcher for longer ones */
 static bool match_like_device(const HostProg &hp, uint32_t at, const HostStr &s, uint32_t len,
-                              const uint32_t *sets)
+                              uint32_t skip, const uint32_t *sets)
 {
     if (len > MCX_OCC_MAX_LEN)
         return mcx_prog_match(hp, at, s, len, sets);
@@ -48,8 +48,7 @@ static bool match_like_device(const HostProg &hp, uint32_t at, const HostStr &s,
     memset(&occ, 0, sizeof occ);
     for (uint32_t q = 0; q < len; ++q)
         occ.t[s.byte(q)] |= (uint64_t)1 << q;
-    bool a = mcx_prog_match_occ(hp, at, occ, len, sets);
-    return a;
+    return mcx_prog_match_occ(hp, at, s, occ, len, skip, sets);
 }
 
 static void normalize(std::string &s, bool *bad)
@@ -94,13 +93,13 @@ int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t 
     if (rc != 0)
         return rc;
     std::vector<uint32_t> prog;
-    mcx_emit_program(ir, prog);
+    mcx_emit_program(ir, 0u, prog);
     prog.insert(prog.end(), 4, 0u); /* read-ahead room */
     HostStr s{(const uint8_t *)string, sn};
     HostProg hp{prog.data()};
     const uint32_t *sets = t.sets.empty() ? nullptr : t.sets.data();
     int r = mcx_prog_match(hp, 0u, s, sn, sets) ? 1 : 0;
-    if (sn <= MCX_OCC_MAX_LEN && (match_like_device(hp, 0u, s, sn, sets) ? 1 : 0) != r)
+    if (sn <= MCX_OCC_MAX_LEN && (match_like_device(hp, 0u, s, sn, 0u, sets) ? 1 : 0) != r)
         return -100; /* the two matchers disagree */
     return r;
 }
@@ -144,10 +143,10 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
                 mcx_key_hash(kw, L, a, b);
                 for (size_t at = a & mask; t.slots[at].count != 0; at = (at + 1) & mask) {
                     const mcx_slot_t &sl = t.slots[at];
-                    if (sl.h1 != a || sl.h2 != b)
+                    if (sl.h1 != a || sl.h2 != b || memcmp(sl.key, kw, sizeof kw) != 0)
                         continue;
                     for (uint32_t k = sl.start; k < sl.start + sl.count; ++k) {
-                        if (!mcx_sig_pass(t.sig[k], bloom))
+                        if (!mcx_sig_pass(t.sigorig[2 * (size_t)k], bloom))
                             continue;
                         const uint32_t *slot = &t.slot[(size_t)k * MCX_SLOT_WORDS];
                         HostProg hp{slot};
@@ -156,9 +155,10 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
                             hp.p = t.ext.data();
                             at = slot[1];
                         }
-                        if (match_like_device(hp, at, s, len, sets)) {
-                            if (t.orig[k] < first)
-                                first = t.orig[k];
+                        /* the key's bytes were compared by the probe */
+                        if (match_like_device(hp, at, s, len, MCX_HDR_KEYLEN(slot[0]), sets)) {
+                            if (t.sigorig[2 * (size_t)k + 1] < first)
+                                first = t.sigorig[2 * (size_t)k + 1];
                             ++cnt;
                         }
                     }

@@ -1,4 +1,4 @@
-"""Timing helper: K1 device time per launch on configs[1] (debug switch MCX_K1_STOP honoured)."""
+"""Timing helper: K1 device time per launch on configs[1] ."""
 import os
 import sys
 
@@ -19,5 +19,5 @@ for reps in [int(x) for x in os.environ.get("K1_REPS", "200").split(",")]:
     ctx.timer_begin()
     for _ in range(reps):
         ctx.alias_match_dev(dS.ptr, dO.ptr, N, dF.ptr, dC.ptr)
-    print("stop=%s N=%d P=%d reps=%d us/launch %.2f" % (os.environ.get("MCX_K1_STOP", "0"), N, P, reps,
+    print("N=%d P=%d reps=%d us/launch %.2f" % (N, P, reps,
                                                        ctx.timer_end() * 1000 / reps))
