@@ -1,0 +1,84 @@
+/*
+ * mcx_internal.h - the context behind include/mcx.h and small helpers shared by
+ * the translation units of libmontecarlo.so (not installed, not part of the ABI).
+ */
+#ifndef MCX_INTERNAL_H
+#define MCX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <string>
+
+#include "../../include/mcx.h"
+#include "mcx_prog.h"
+
+/* ------------------------------------------------------------------------- */
+/* context                                                                    */
+/* ------------------------------------------------------------------------- */
+
+struct mcx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    /* alias table */
+    uint32_t P = 0;
+    bool table_loaded = false;
+    bool norm_dash = false;
+    uint32_t n_indexed = 0;          /* patterns that can match anything       */
+    uint32_t *d_slot = nullptr;      /* n_indexed program slots, index order   */
+    uint32_t *d_ext = nullptr;       /* overflow programs                      */
+    uint32_t *d_sigorig = nullptr;   /* n_indexed x {gram signature, position} */
+    mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
+    uint32_t slot_mask = 0;
+    uint32_t nlens = 0;
+    uint32_t lens[MCX_KEY_MAX + 1] = {0};
+    uint32_t *d_sets = nullptr;
+    uint32_t *d_amod = nullptr;
+    uint8_t *d_hwtag = nullptr;
+    uint64_t table_bytes = 0;
+
+    /* dependency graph: forward CSR as given, reverse CSR built at load */
+    uint32_t V = 0, E = 0;
+    bool graph_loaded = false;
+    uint32_t *d_rowptr = nullptr, *d_col = nullptr;
+    uint32_t *d_rrowptr = nullptr, *d_rcol = nullptr;
+    uint32_t *d_part = nullptr;    /* row blocks of the reverse CSR (n_part + 1) */
+    uint32_t n_part = 0;
+    uint32_t *d_queue[2] = {nullptr, nullptr}; /* BFS frontiers, V entries each */
+    uint32_t *d_bfs = nullptr;     /* per-level frontier sizes + edge counter  */
+    uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */
+};
+
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+            return MCX_E_HIP;                                                          \
+        }                                                                              \
+    } while (0)
+
+static inline int mcx_set_device(mcx_ctx *ctx)
+{
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return 0;
+}
+
+template <class T>
+static int mcx_dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
+{
+    size_t bytes = sizeof(T) * (count ? count : 1);
+    HIPCHK(ctx, hipMalloc((void **)d_out, bytes));
+    if (count)
+        HIPCHK(ctx, hipMemcpyAsync(*d_out, src, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+void mcx_free_table(mcx_ctx *ctx);
+void mcx_free_graph(mcx_ctx *ctx);
+
+#endif /* MCX_INTERNAL_H */

@@ -1,0 +1,486 @@
+/*
+ * mcx_k2.hip - K2: the module dependency graph.
+ *   K2a dep_flags   has-holders / in-use / root bits and holder counts,
+ *   K2b dep_closure reachability among loaded modules (frontier BFS),
+ * HIP kernels for gfx950 and their C ABI entry points (include/mcx.h).
+ * There is no CPU path here: every entry point needs a HIP device.
+ *
+ * Layout in HBM (built once by mcx_dep_graph_load):
+ *   rowptr/col    forward CSR, u -> col[k]: "u needs col[k]"
+ *   rrowptr/rcol  reverse CSR, v -> rcol[k]: "rcol[k] holds v" (the content of
+ *                 /sys/module/<v>/holders)
+ *   part          row blocks of the reverse CSR for K2a: consecutive rows, at
+ *                 most K2_ROWS rows and about K2_EDGES edges each (a row with
+ *                 more edges than that is a block of its own)
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "mcx_internal.h"
+
+#define K2_THREADS 256
+#define K2_ROWS 256u
+#define K2_EDGES 4096u
+#define K2B_BLOCKS 1024u  /* grid of one BFS level; strides over the frontier */
+#define K2B_BATCH 8u      /* levels enqueued between two looks at the queue size */
+#define K2B_MAX_LEVELS 4096u
+
+/* ------------------------------------------------------------------------- */
+/* K2a: one block = one row block of the reverse CSR.                         */
+/* Every edge (holder u of row v) is read once, coalesced; its row is found   */
+/* by bisection in the block's slice of rrowptr held in LDS; loaded holders   */
+/* are counted per row in LDS; the block then writes the flags and counts of  */
+/* its own rows.  No global atomics, no zero-filled scratch.                   */
+/* ------------------------------------------------------------------------- */
+
+__global__ void __launch_bounds__(K2_THREADS)
+k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ rcol,
+              const uint32_t *__restrict__ part, const uint8_t *__restrict__ in_flags,
+              uint8_t *__restrict__ out_flags, uint32_t *__restrict__ refcnt)
+{
+    __shared__ uint32_t rp[K2_ROWS + 1];
+    __shared__ uint32_t cnt[K2_ROWS];
+    __shared__ uint32_t wsum[K2_THREADS / 64];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r0 = part[blockIdx.x], r1 = part[blockIdx.x + 1];
+    const uint32_t R = r1 - r0;
+    for (uint32_t i = tid; i <= R; i += K2_THREADS)
+        rp[i] = rrowptr[r0 + i];
+    if (tid < K2_ROWS)
+        cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t e0 = rp[0], e1 = rp[R];
+
+    if (R == 1u) {
+        /* one (possibly very long) row: count in registers, reduce once */
+        uint32_t mine = 0;
+        for (uint32_t e = e0 + tid; e < e1; e += K2_THREADS)
+            mine += in_flags[rcol[e]] & MCX_F_LOADED;
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1)
+            mine += __shfl_down(mine, d, 64);
+        if ((tid & 63u) == 0)
+            wsum[tid >> 6] = mine;
+        __syncthreads();
+        if (tid == 0)
+            cnt[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    } else {
+        for (uint32_t e = e0 + tid; e < e1; e += K2_THREADS) {
+            const uint32_t u = rcol[e];
+            if (!(in_flags[u] & MCX_F_LOADED))
+                continue;
+            uint32_t lo = 0, hi = R; /* largest i with rp[i] <= e */
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rp[mid] <= e)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            atomicAdd(&cnt[lo], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < R) {
+        const uint32_t v = r0 + tid;
+        const uint32_t f = in_flags[v], h = cnt[tid];
+        uint32_t o = 0;
+        if (f & MCX_F_LOADED) {
+            if (h)
+                o |= MCX_O_HAS_HOLDERS;
+            if ((f & MCX_F_BOUND) || h)
+                o |= MCX_O_IN_USE;
+            if ((f & MCX_F_SAFE) && !h)
+                o |= MCX_O_ROOT;
+        }
+        out_flags[v] = (uint8_t)o;
+        if (refcnt)
+            refcnt[v] = (f & MCX_F_LOADED) ? h + ((f & MCX_F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* K2b: level-synchronous frontier BFS.                                       */
+/* ------------------------------------------------------------------------- */
+
+/* counters: qsize[level] = vertices in the frontier of that level (zeroed once
+ * per call), followed by one 64-bit count of adjacency entries scanned */
+struct k2b_state_t {
+    uint32_t *qsize;              /* K2B_MAX_LEVELS + 1 words */
+    unsigned long long *edges;
+};
+
+__global__ void __launch_bounds__(K2_THREADS)
+k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags, uint32_t V,
+         uint32_t *__restrict__ out, uint32_t *__restrict__ queue, uint32_t *__restrict__ qsize0)
+{
+    /* one thread per bitmap word: the result word is the seed word restricted
+     * to loaded modules, written whole, so the bitmap needs no clearing */
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t W = (V + 31u) / 32u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t keep = 0;
+    if (w < W) {
+        uint32_t bits = seed[w];
+        while (bits) {
+            const uint32_t b = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            const uint32_t v = 32u * w + b;
+            if (v < V && (in_flags[v] & MCX_F_LOADED))
+                keep |= 1u << b;
+        }
+        out[w] = keep;
+    }
+    /* one queue reservation per wave: exclusive scan of the per-lane counts */
+    const uint32_t mine = (uint32_t)__popc(keep);
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d)
+            incl += o;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0u)
+        return;
+    uint32_t at = 0;
+    if (lane == 0)
+        at = atomicAdd(qsize0, total);
+    at = __shfl(at, 0, 64) + incl - mine;
+    while (keep) {
+        const uint32_t b = (uint32_t)__builtin_ctz(keep);
+        keep &= keep - 1u;
+        queue[at++] = 32u * w + b;
+    }
+}
+
+/* claim u for the closure; true if this call set its bit */
+__device__ __forceinline__ bool k2b_claim(uint32_t *out, const uint8_t *in_flags, uint32_t u)
+{
+    if (!(in_flags[u] & MCX_F_LOADED))
+        return false;
+    const uint32_t bit = 1u << (u & 31u);
+    if (out[u >> 5] & bit)
+        return false;
+    return !(atomicOr(&out[u >> 5], bit) & bit);
+}
+
+/*
+ * One level.  A frontier vertex with fewer than 32 neighbours is expanded by
+ * its own lane; the others are taken one at a time by the whole wave, which
+ * then reads the adjacency 64 entries per step (a hub with 10^4 holders would
+ * otherwise keep one lane busy for 10^4 steps).  New vertices are appended to
+ * the next frontier with one queue reservation per wave step.
+ */
+__global__ void __launch_bounds__(K2_THREADS)
+k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+           const uint8_t *__restrict__ in_flags, const uint32_t *__restrict__ frontier,
+           uint32_t *__restrict__ out, uint32_t *__restrict__ next, k2b_state_t st, uint32_t level)
+{
+    const uint32_t n = st.qsize[level];
+    if (n == 0u)
+        return;
+    uint32_t *nsize = &st.qsize[level + 1u];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned long long scanned = 0;
+    /* all lanes of a wave run the same number of rounds */
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t base = first - lane; base < n; base += stride) {
+        const uint32_t t = base + lane;
+        uint32_t k0 = 0, k1 = 0;
+        if (t < n) {
+            const uint32_t v = frontier[t];
+            k0 = rowptr[v];
+            k1 = rowptr[v + 1];
+            scanned += k1 - k0;
+        }
+        const bool big = (k1 - k0) >= 32u;
+        /* short adjacency lists: one entry per lane and step, the new
+         * vertices of a step appended with one queue reservation per wave */
+        {
+            uint32_t k = big ? k1 : k0;
+            while (__any(k < k1)) {
+                bool got = false;
+                uint32_t u = 0;
+                if (k < k1) {
+                    u = col[k];
+                    got = k2b_claim(out, in_flags, u);
+                    ++k;
+                }
+                const unsigned long long m = __ballot(got);
+                if (m) {
+                    uint32_t at = 0;
+                    if (lane == 0)
+                        at = atomicAdd(nsize, (uint32_t)__popcll(m));
+                    at = __shfl(at, 0, 64);
+                    if (got)
+                        next[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = u;
+                }
+            }
+        }
+        /* long ones: the wave takes them in turn */
+        unsigned long long todo = __ballot(big);
+        while (todo) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t b0 = __shfl(k0, src, 64), b1 = __shfl(k1, src, 64);
+            for (uint32_t kb = b0; kb < b1; kb += 64u) {
+                const uint32_t k = kb + lane;
+                bool got = false;
+                uint32_t u = 0;
+                if (k < b1) {
+                    u = col[k];
+                    got = k2b_claim(out, in_flags, u);
+                }
+                const unsigned long long m = __ballot(got);
+                if (m) {
+                    uint32_t at = 0;
+                    if (lane == 0)
+                        at = atomicAdd(nsize, (uint32_t)__popcll(m));
+                    at = __shfl(at, 0, 64);
+                    if (got)
+                        next[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = u;
+                }
+            }
+        }
+    }
+    /* one add per wave */
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1)
+        scanned += __shfl_down(scanned, d, 64);
+    if (lane == 0 && scanned)
+        atomicAdd(st.edges, scanned);
+}
+
+/* ------------------------------------------------------------------------- */
+/* C ABI                                                                      */
+/* ------------------------------------------------------------------------- */
+
+extern "C" {
+
+int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col, uint32_t V, uint32_t E)
+{
+    if (!ctx || !rowptr || (E && !col))
+        return MCX_E_BAD_ARG;
+    if (rowptr[0] != 0 || rowptr[V] != E) {
+        ctx->err = "rowptr[0] must be 0 and rowptr[V] must be E";
+        return MCX_E_BAD_ARG;
+    }
+    for (uint32_t u = 0; u < V; ++u)
+        if (rowptr[u + 1] < rowptr[u]) {
+            ctx->err = "rowptr not monotonic";
+            return MCX_E_BAD_ARG;
+        }
+    for (uint32_t k = 0; k < E; ++k)
+        if (col[k] >= V) {
+            ctx->err = "col entry out of range";
+            return MCX_E_BAD_ARG;
+        }
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    /* reverse CSR (holders of each module) by counting sort */
+    std::vector<uint32_t> rrow((size_t)V + 2, 0), rcol(E ? E : 1);
+    for (uint32_t k = 0; k < E; ++k)
+        rrow[(size_t)col[k] + 2]++;
+    for (uint32_t v = 0; v < V; ++v)
+        rrow[(size_t)v + 2] += rrow[(size_t)v + 1];
+    for (uint32_t u = 0; u < V; ++u)
+        for (uint32_t k = rowptr[u]; k < rowptr[u + 1]; ++k)
+            rcol[rrow[(size_t)col[k] + 1]++] = u;
+    /* rrow[0..V] is now the reverse row pointer; cut it into row blocks */
+    std::vector<uint32_t> part;
+    part.push_back(0);
+    for (uint32_t r = 0; r < V;) {
+        uint32_t end = r + 1;
+        while (end < V && end - r < K2_ROWS && rrow[end + 1] - rrow[r] <= K2_EDGES)
+            ++end;
+        part.push_back(end);
+        r = end;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    mcx_free_graph(ctx);
+    int rc;
+    if ((rc = mcx_dev_upload(ctx, &ctx->d_rowptr, rowptr, (size_t)V + 1)) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_col, col, (size_t)E)) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_rrowptr, rrow.data(), (size_t)V + 1)) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_rcol, rcol.data(), (size_t)E)) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_part, part.data(), part.size())) != 0) {
+        mcx_free_graph(ctx);
+        return rc;
+    }
+    size_t vb = 4 * ((size_t)V ? V : 1);
+    if (hipMalloc((void **)&ctx->d_queue[0], vb) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_queue[1], vb) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_bfs, 4 * (size_t)(K2B_MAX_LEVELS + 4)) != hipSuccess) {
+        mcx_free_graph(ctx);
+        ctx->err = "hipMalloc of graph scratch failed";
+        return MCX_E_NOMEM;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->V = V;
+    ctx->E = E;
+    ctx->n_part = (uint32_t)part.size() - 1u;
+    ctx->graph_loaded = true;
+    return MCX_OK;
+}
+
+int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, void *d_refcnt)
+{
+    if (!ctx || !d_in_flags || !d_out_flags)
+        return MCX_E_BAD_ARG;
+    if (!ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    if (ctx->V == 0)
+        return MCX_OK;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    k2_flags_rows<<<ctx->n_part, K2_THREADS, 0, ctx->stream>>>(ctx->d_rrowptr, ctx->d_rcol, ctx->d_part,
+                                                              (const uint8_t *)d_in_flags,
+                                                              (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
+    HIPCHK(ctx, hipGetLastError());
+    return MCX_OK;
+}
+
+int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uint32_t *refcnt)
+{
+    if (!ctx || !in_flags || !out_flags)
+        return MCX_E_BAD_ARG;
+    if (!ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    uint32_t V = ctx->V;
+    if (V == 0)
+        return MCX_OK;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint32_t *d_ref = nullptr;
+    int rc = MCX_OK;
+    if (hipMalloc((void **)&d_in, V) != hipSuccess || hipMalloc((void **)&d_out, V) != hipSuccess ||
+        (refcnt && hipMalloc((void **)&d_ref, 4 * (size_t)V) != hipSuccess)) {
+        ctx->err = "hipMalloc failed";
+        rc = MCX_E_NOMEM;
+    }
+    if (rc == MCX_OK && hipMemcpyAsync(d_in, in_flags, V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = MCX_E_HIP;
+    if (rc == MCX_OK)
+        rc = mcx_dep_flags_dev(ctx, d_in, d_out, d_ref);
+    if (rc == MCX_OK && hipMemcpyAsync(out_flags, d_out, V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = MCX_E_HIP;
+    if (rc == MCX_OK && refcnt &&
+        hipMemcpyAsync(refcnt, d_ref, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = MCX_E_HIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MCX_OK)
+        rc = MCX_E_HIP;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    (void)hipFree(d_ref);
+    return rc;
+}
+
+int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed_bitmap, void *d_out_bitmap,
+                        int direction, uint64_t *edges_scanned, uint32_t *levels)
+{
+    if (!ctx || !d_in_flags || !d_seed_bitmap || !d_out_bitmap ||
+        (direction != MCX_CLOSURE_HOLDERS && direction != MCX_CLOSURE_DEPS))
+        return MCX_E_BAD_ARG;
+    if (!ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    if (edges_scanned)
+        *edges_scanned = 0;
+    if (levels)
+        *levels = 0;
+    const uint32_t V = ctx->V;
+    if (V == 0)
+        return MCX_OK;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    const uint32_t *rp = direction == MCX_CLOSURE_HOLDERS ? ctx->d_rrowptr : ctx->d_rowptr;
+    const uint32_t *cl = direction == MCX_CLOSURE_HOLDERS ? ctx->d_rcol : ctx->d_col;
+    const uint32_t W = (V + 31) / 32;
+    k2b_state_t st;
+    st.qsize = ctx->d_bfs;
+    st.edges = (unsigned long long *)(ctx->d_bfs + K2B_MAX_LEVELS + 2); /* 8-byte aligned */
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_bfs, 0, 4 * (size_t)(K2B_MAX_LEVELS + 4), ctx->stream));
+    k2b_seed<<<(W + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
+        (const uint32_t *)d_seed_bitmap, (const uint8_t *)d_in_flags, V, (uint32_t *)d_out_bitmap,
+        ctx->d_queue[0], &st.qsize[0]);
+    /* levels are enqueued K2B_BATCH at a time; a level whose frontier is empty
+     * returns at once, and the queue sizes of a batch tell where the search
+     * ended.  A path visits each vertex once, so V levels always suffice. */
+    uint32_t lv = 0;
+    uint32_t *sizes = ctx->h_pinned;                                  /* K2B_BATCH words */
+    unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 16);
+    bool done = false;
+    while (!done) {
+        if (lv + K2B_BATCH > K2B_MAX_LEVELS) {
+            ctx->err = "closure deeper than 4096 levels";
+            return MCX_E_TOO_LARGE;
+        }
+        for (uint32_t b = 0; b < K2B_BATCH; ++b) {
+            const uint32_t level = lv + b;
+            k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags,
+                                                                  ctx->d_queue[level & 1u],
+                                                                  (uint32_t *)d_out_bitmap,
+                                                                  ctx->d_queue[(level + 1u) & 1u], st, level);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(sizes, &st.qsize[lv], 4 * K2B_BATCH, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_edges, st.edges, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t b = 0; b < K2B_BATCH; ++b) {
+            if (sizes[b] == 0u) {
+                done = true;
+                break;
+            }
+            ++lv;
+        }
+    }
+    if (edges_scanned)
+        *edges_scanned = *h_edges;
+    if (levels)
+        *levels = lv;
+    return MCX_OK;
+}
+
+int mcx_dep_closure(mcx_ctx *ctx, const uint8_t *in_flags, const uint32_t *seed_bitmap, uint32_t *out_bitmap,
+                    int direction, uint64_t *edges_scanned, uint32_t *levels)
+{
+    if (!ctx || !in_flags || !seed_bitmap || !out_bitmap)
+        return MCX_E_BAD_ARG;
+    if (!ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    uint32_t V = ctx->V;
+    if (V == 0)
+        return MCX_OK;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    size_t wb = 4 * (size_t)((V + 31) / 32);
+    uint8_t *d_in = nullptr;
+    uint32_t *d_seed = nullptr, *d_out = nullptr;
+    int rc = MCX_OK;
+    if (hipMalloc((void **)&d_in, V) != hipSuccess || hipMalloc((void **)&d_seed, wb) != hipSuccess ||
+        hipMalloc((void **)&d_out, wb) != hipSuccess) {
+        ctx->err = "hipMalloc failed";
+        rc = MCX_E_NOMEM;
+    }
+    if (rc == MCX_OK && (hipMemcpyAsync(d_in, in_flags, V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                         hipMemcpyAsync(d_seed, seed_bitmap, wb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
+        rc = MCX_E_HIP;
+    if (rc == MCX_OK)
+        rc = mcx_dep_closure_dev(ctx, d_in, d_seed, d_out, direction, edges_scanned, levels);
+    if (rc == MCX_OK && hipMemcpyAsync(out_bitmap, d_out, wb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = MCX_E_HIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MCX_OK)
+        rc = MCX_E_HIP;
+    (void)hipFree(d_in);
+    (void)hipFree(d_seed);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+} /* extern "C" */

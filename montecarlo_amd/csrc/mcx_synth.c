@@ -466,10 +466,16 @@ static uint32_t gen_row(uint64_t seed, uint32_t u, uint32_t mean_deg, uint32_t *
         ++d;
     uint32_t n = 0;
     for (uint32_t k = 0; k < d; ++k) {
-        /* product of two uniforms: density -ln(x), mass near 0 */
+        /* product of two uniforms: density -ln(x), mass near 0; one edge in
+         * eight goes to a small set of "core" modules instead (the first few
+         * hundred ids, again biased towards 0), which gives hubs with 10^4
+         * and more holders at V = 10^6 */
         uint64_t a = rng_next(&r) >> 32, b = rng_next(&r) >> 32;
         uint64_t f = (a * b) >> 32;
-        uint32_t v = (uint32_t)(((uint64_t)u * f) >> 32);
+        uint32_t span = u;
+        if ((rng_next(&r) & 7u) == 0u && u > 512u)
+            span = 512u;
+        uint32_t v = (uint32_t)(((uint64_t)span * f) >> 32);
         uint32_t q = 0;
         while (q < n && out[q] < v)
             ++q;
