@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--graph-vertices", type=int, default=1_000_000)
     ap.add_argument("--graph-degree", type=int, default=10)
+    ap.add_argument("--shard", choices=["strings", "patterns"], default="strings",
+                    help="with --gpus N>1: every rank its own strings against the whole table (default, no "
+                         "collective), or every rank a slice of the table against all strings + MIN/SUM all-reduce")
     ap.add_argument("--no-k2", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -48,6 +51,22 @@ def k1_algorithmic_bytes(S, s_off, A, a_off):
     """every input byte once + first_idx and count: |S| + 4(N+1) + |A| + 4(P+1) + 4P + 8N"""
     N, P = len(s_off) - 1, len(a_off) - 1
     return len(S) + 4 * (N + 1) + len(A) + 4 * (P + 1) + 4 * P + 8 * N
+
+
+def measured_traffic(N, P):
+    """HBM bytes per K1 launch from rocprofv3 PMC passes of this same command
+    (FETCH_SIZE doubled, as gfx950 reports half of a streamed read, plus
+    WRITE_SIZE; both in KiB), kept in profiles/k1_traffic.json by
+    scripts/pmc_traffic.py.  None when no measurement of this workload is on file."""
+    path = os.path.join(ROOT, "profiles", "k1_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("strings") == N and rec.get("patterns") == P:
+            return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline_k1(A, a_off, S, s_off, budget_s):
@@ -109,17 +128,32 @@ def main():
     stream = torch.cuda.Stream(device=local_rank)
 
     N, P = args.strings, args.patterns
-    A, a_off, a_mod = synth.alias_table(args.seed, P)
-    # rank r owns strings [r*N, (r+1)*N) of the N*world batch
-    S, s_off = synth.modalias_strings(args.seed, P, N * world, i0=rank * N, i1=(rank + 1) * N)
+    by_pattern = world > 1 and args.shard == "patterns"
+    from montecarlo_amd import shard
+
+    if by_pattern:
+        # BASELINE configs[3] layout: rank r holds table slice [j0, j1) and sees all N strings
+        j0, j1 = shard.shard_range(P, rank, world)
+        A, a_off, a_mod = synth.alias_table(args.seed, P, j0, j1)
+        S, s_off = synth.modalias_strings(args.seed, P, N)
+    else:
+        # rank r owns strings [r*N, (r+1)*N) of the N*world batch, whole table everywhere
+        j0 = 0
+        A, a_off, a_mod = synth.alias_table(args.seed, P)
+        S, s_off = synth.modalias_strings(args.seed, P, N * world, i0=rank * N, i1=(rank + 1) * N)
 
     ctx = Context(local_rank, stream=stream.cuda_stream)
     ctx.alias_table_load(A, a_off, a_mod)
     d_S, d_off = ctx.to_device(S), ctx.to_device(s_off)
-    d_first, d_count = ctx.alloc(4 * N), ctx.alloc(4 * N)
+    # outputs live in torch tensors so that the pattern-sharded mode can all-reduce them in place
+    t_first = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
+    t_count = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
 
     def step():
-        ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, d_first.ptr, d_count.ptr)
+        ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, t_first.data_ptr(), t_count.data_ptr())
+        if by_pattern:
+            with torch.cuda.stream(stream):
+                shard.combine_pattern_shards(t_first, t_count, j0)
 
     def fence():
         if dist is not None:
@@ -142,12 +176,12 @@ def main():
         wall, dev_ms = float(t[0]), float(t[1])
 
     # results of the last step must be the oracle's (cheap: a 64-string sample)
-    first = d_first.download(np.uint32, N)
-    count = d_count.download(np.uint32, N)
+    first = shard.as_u32(t_first)
+    count = shard.as_u32(t_count)
 
     out = None
     if rank == 0:
-        pairs_per_step = N * P * world
+        pairs_per_step = N * P if by_pattern else N * P * world
         alg_bytes = k1_algorithmic_bytes(S, s_off, A, a_off)
         dev_s_per_launch = dev_ms / 1e3 / args.steps
         achieved = alg_bytes / dev_s_per_launch / 1e9
@@ -160,16 +194,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if by_pattern else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: {N} modalias strings x {P} alias patterns per GPU, seed {args.seed}, "
-                            "strings and table resident in HBM",
+                "workload": (f"configs[3] layout: {N} modalias strings x {P} alias patterns, table cut in {world} "
+                             f"slices, MIN/SUM all-reduce per step, seed {args.seed}") if by_pattern else
+                            (f"configs[1]: {N} modalias strings x {P} alias patterns per GPU, seed {args.seed}, "
+                             "strings and table resident in HBM"),
                 "strings_per_gpu": N,
                 "patterns": P,
-                "sharding": "strings" if world > 1 else "none",
+                "sharding": ("patterns" if by_pattern else "strings") if world > 1 else "none",
             },
             "roofline": {
                 "bound": "hbm",
@@ -177,8 +213,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "k1_match_tiled (+k1_init), device time per step from HIP events",
+                "traffic": measured_traffic(N, P),
+                "kernel": "k1_match_indexed, one launch per step, device time from HIP events on its stream",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "device_us_per_launch": dev_s_per_launch * 1e6,
             },
@@ -191,11 +227,13 @@ def main():
         import oracle
 
         n_chk = min(N, 64)
+        if by_pattern:  # the combined result is against the whole table
+            A, a_off, a_mod = synth.alias_table(args.seed, P)
         o_first, o_count = oracle.alias_match(A, a_off, S, s_off, i0=0, i1=n_chk)
         if not (np.array_equal(first[:n_chk], o_first) and np.array_equal(count[:n_chk], o_count)):
             raise SystemExit("bench: GPU result differs from the oracle")
         out["cpu_baseline"] = cpu_baseline_k1(A, a_off, S, s_off, args.cpu_seconds)
-    for b in (d_S, d_off, d_first, d_count):
+    for b in (d_S, d_off):
         b.free()
     ctx.close()
     if dist is not None:

@@ -1,0 +1,86 @@
+"""N>1 host logic on CPU: two gloo ranks.  The per-rank match results come from the
+CPU oracle here (there is no GPU on this side, and the product has no CPU path);
+what is under test is the sharding arithmetic and the MIN/SUM combine that the
+pattern-sharded mode runs over RCCL on the GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from montecarlo_amd import shard, synth
+
+SEED, P, N = 21, 1500, 240
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # pattern-sharded: this rank's slice of the table, all strings
+    j0, j1 = shard.shard_range(P, rank, world)
+    A, a_off, a_mod = synth.alias_table(SEED, P, j0, j1)
+    S, s_off = synth.modalias_strings(SEED, P, N)
+    first, count = oracle.alias_match(A, a_off, S, s_off)
+    f32, c32 = shard.as_i32(first), shard.as_i32(count)
+    shard.combine_pattern_shards(f32, c32, j0)
+    np.save(os.path.join(out_dir, f"pat_first_{rank}.npy"), shard.as_u32(f32))
+    np.save(os.path.join(out_dir, f"pat_count_{rank}.npy"), shard.as_u32(c32))
+    # string-sharded: the whole table, this rank's slice of the strings, no collective
+    i0, i1 = shard.shard_range(N, rank, world)
+    A, a_off, a_mod = synth.alias_table(SEED, P)
+    Sr, sr_off = synth.modalias_strings(SEED, P, N, i0, i1)
+    first, count = oracle.alias_match(A, a_off, Sr, sr_off)
+    np.save(os.path.join(out_dir, f"str_first_{rank}.npy"), first)
+    np.save(os.path.join(out_dir, f"str_count_{rank}.npy"), count)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            cuts = [shard.shard_range(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.shard_range(10, 2, 2)
+
+
+def test_first_index_order_mapping():
+    f = shard.as_i32(np.array([0, 5, 0xFFFFFFFF, 7], dtype=np.uint32))
+    shard.globalize_first(f, 100)
+    g = shard.as_i32(np.array([3, 0xFFFFFFFF, 0xFFFFFFFF, 2], dtype=np.uint32))
+    shard.globalize_first(g, 0)
+    m = torch.minimum(f, g)
+    m.bitwise_xor_(-2147483648)
+    assert shard.as_u32(m).tolist() == [3, 105, 0xFFFFFFFF, 2]
+
+
+def test_two_rank_gloo_combine(tmp_path, oracle_mod):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    A, a_off, a_mod = synth.alias_table(SEED, P)
+    S, s_off = synth.modalias_strings(SEED, P, N)
+    first, count = oracle_mod.alias_match(A, a_off, S, s_off)
+    assert (count > 0).sum() > N // 2
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"pat_first_{r}.npy"), first)
+        assert np.array_equal(np.load(tmp_path / f"pat_count_{r}.npy"), count)
+    sf = np.concatenate([np.load(tmp_path / f"str_first_{r}.npy") for r in range(world)])
+    sc = np.concatenate([np.load(tmp_path / f"str_count_{r}.npy") for r in range(world)])
+    assert np.array_equal(sf, first) and np.array_equal(sc, count)
