@@ -165,6 +165,63 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                         void *d_out_bitmap, int direction,
                         uint64_t *edges_scanned, uint32_t *levels);
 
+/* ---- safe-module filter and the fleet pipeline --------------------------- */
+
+/*
+ * Name stages of the reference's is_safe_module (desktop/ui.py:1391-1518):
+ * safe_out[i] = 0 when name i is one of the 113 core module names
+ * (ui.py:1402-1470) or starts with one of the 56 prefixes (ui.py:1486-1514),
+ * else 1.  Names are packed like patterns: name i = names[name_off[i] ..
+ * name_off[i+1]).  Host only; needs no context and no device.  The third
+ * stage of the filter ("owns a hardware alias") is mcx_alias_hw_flags.
+ */
+int mcx_safe_module_names(const char *names, const uint32_t *name_off, uint32_t n,
+                          uint8_t *safe_out);
+int mcx_safe_table_sizes(uint32_t *n_core, uint32_t *n_prefix);
+
+/*
+ * The dashboard's "loaded modules" list (desktop/ui.py:1565-1599) for H hosts
+ * at once, against the loaded alias table and dependency graph (module ids of
+ * the table's a_mod and of the graph are the same ids).
+ *
+ * Host h owns the devices dev_off[h] .. dev_off[h+1] of the string batch
+ * (S, s_off, N; dev_off[H] = N) and the extra loaded modules
+ * extra_ids[extra_off[h] .. extra_off[h+1]) (modules loaded by hand or at
+ * boot, without a device).  Per host:
+ *   used    = { a_mod[first_idx[i]] : i a device of h with a match }
+ *             (the drivers the device list shows, ui.py:1567)
+ *   loaded  = used + extras, closed under "needs" (what /proc/modules holds
+ *             once those modules are in)
+ *   held[v] = some loaded u needs v (mc_module_has_holders,
+ *             montecarlo/libmontecarlo.c:446-473, asked at ui.py:1575)
+ *   listed  = loaded, not used, safe_name[v] and hw_alias[v] (is_safe_module,
+ *             ui.py:1571), not held.
+ * Output in CSR form: root_off[h] .. root_off[h+1] index root_ids, module ids
+ * ascending within a host.  *total_out = root_off[H].  When root_ids (cap
+ * entries) is too small the call returns MCX_E_TOO_LARGE with *total_out and
+ * root_off filled in, so the caller can allocate and call again.  Module ids
+ * >= V in a_mod or extra_ids are ignored.  A graph with a dependency cycle is
+ * refused (MCX_E_BAD_ARG), so is a table loaded with MCX_TABLE_NORMALIZE_DASH.
+ * Device memory: 8 * V * ceil(H/32) bytes of scratch; a fleet that does not fit
+ * is split by the caller into groups of hosts (hosts are independent).
+ * Every listed module is idle in the sense of mc_driver_is_in_use
+ * (montecarlo/libmontecarlo.c:573-725): it drives no device and has no holder.
+ */
+int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N,
+                    const uint32_t *dev_off, uint32_t H,
+                    const uint32_t *extra_off, const uint32_t *extra_ids,
+                    const uint8_t *safe_name,
+                    uint32_t *root_off, uint32_t *root_ids, uint64_t cap,
+                    uint64_t *total_out);
+/* Same with device buffers; X = extra_off[H].  Enqueues, then waits once for
+ * the total (it decides whether root_ids is large enough). */
+int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N,
+                        const void *d_dev_off, uint32_t H,
+                        const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                        const void *d_safe_name,
+                        void *d_root_off, void *d_root_ids, uint64_t cap,
+                        uint64_t *total_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,8 @@ from .binding import (  # noqa: F401
     CLOSURE_HOLDERS,
     CLOSURE_DEPS,
     TABLE_NORMALIZE_DASH,
+    safe_module_names,
+    pack_strings,
 )
 from . import synth  # noqa: F401
 

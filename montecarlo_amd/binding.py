@@ -82,6 +82,18 @@ def load_library():
             ctypes.c_int,
             [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)],
         ),
+        "mcx_safe_module_names": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
+        "mcx_safe_table_sizes": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
+        "mcx_fleet_roots": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64,
+             ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_fleet_roots_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp,
+             ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
+        ),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -286,3 +298,44 @@ class Context:
             "mcx_dep_closure_dev",
         )
         return edges.value, levels.value
+
+    def fleet_roots(self, S, s_off, dev_off, extra_off, extra_ids, safe_name, cap=None):
+        """(root_off, root_ids) of mcx_fleet_roots; sizes root_ids itself when cap is None"""
+        S, s_off = _as(S, np.uint8), _as(s_off, np.uint32)
+        dev_off, extra_off = _as(dev_off, np.uint32), _as(extra_off, np.uint32)
+        extra_ids, safe_name = _as(extra_ids, np.uint32), _as(safe_name, np.uint8)
+        N, H = len(s_off) - 1, len(dev_off) - 1
+        if len(extra_off) != H + 1 or len(safe_name) != self.V:
+            raise ValueError("extra_off needs H+1 entries and safe_name V entries")
+        root_off = np.zeros(H + 1, dtype=np.uint32)
+        total = ctypes.c_uint64()
+        ids = np.zeros(int(cap) if cap else 1, dtype=np.uint32)
+        args = (self.h, _ptr(S), _ptr(s_off), N, _ptr(dev_off), H, _ptr(extra_off), _ptr(extra_ids),
+                _ptr(safe_name), _ptr(root_off))
+        rc = self.lib.mcx_fleet_roots(*args, _ptr(ids), int(cap) if cap else 0, ctypes.byref(total))
+        if rc == -6 and cap is None and total.value < 2**32:
+            ids = np.zeros(total.value, dtype=np.uint32)
+            rc = self.lib.mcx_fleet_roots(*args, _ptr(ids), total.value, ctypes.byref(total))
+        self._check(rc, "mcx_fleet_roots")
+        return root_off, ids[: total.value]
+
+    def fleet_roots_dev(self, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe, d_root_off,
+                        d_root_ids, cap, size_only=False):
+        """returns the total; with size_only a too-small root_ids is not an error"""
+        total = ctypes.c_uint64()
+        rc = self.lib.mcx_fleet_roots_dev(self.h, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X,
+                                          d_safe, d_root_off, d_root_ids, cap, ctypes.byref(total))
+        if not (size_only and rc == -6 and cap < total.value < 2**32):
+            self._check(rc, "mcx_fleet_roots_dev")
+        return total.value
+
+
+def safe_module_names(names):
+    """name stages of the reference's safe-module filter for a list of str/bytes -> uint8[n]"""
+    lib = load_library()
+    arena, off = pack_strings([n.encode() if isinstance(n, str) else n for n in names])
+    out = np.zeros(max(len(names), 1), dtype=np.uint8)
+    rc = lib.mcx_safe_module_names(_ptr(arena) if len(arena) else None, _ptr(off), len(names), _ptr(out))
+    if rc != 0:
+        raise McxError(rc, "mcx_safe_module_names")
+    return out[: len(names)]

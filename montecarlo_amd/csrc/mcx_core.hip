@@ -44,6 +44,9 @@ void mcx_free_graph(mcx_ctx *ctx)
     (void)hipFree(ctx->d_queue[0]);
     (void)hipFree(ctx->d_queue[1]);
     (void)hipFree(ctx->d_bfs);
+    (void)hipFree(ctx->d_lvl_order);
+    ctx->d_lvl_order = nullptr;
+    ctx->lvl_ptr.clear();
     ctx->d_rowptr = ctx->d_col = ctx->d_rrowptr = ctx->d_rcol = ctx->d_part = ctx->d_bfs = nullptr;
     ctx->d_queue[0] = ctx->d_queue[1] = nullptr;
     ctx->n_part = 0;
@@ -116,6 +119,7 @@ void mcx_ctx_destroy(mcx_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
     mcx_free_table(ctx);
     mcx_free_graph(ctx);
+    (void)hipFree(ctx->d_fleet);
     if (ctx->h_pinned)
         (void)hipHostFree(ctx->h_pinned);
     if (ctx->ev0)

@@ -1,0 +1,418 @@
+/*
+ * mcx_fleet.hip - the dashboard's module list for a whole fleet of hosts in one
+ * call: alias match -> used drivers -> loaded set (closed under "needs") ->
+ * holders -> root filter, everything on the device.  Restates per host the loop
+ * of reference desktop/ui.py:1565-1599 (see include/mcx.h for the exact rule).
+ *
+ * Sets of hosts are bit columns.  Two matrices of V rows (modules) by
+ * HW = ceil(H/32) words live in HBM, row-major, bit h%32 of word h/32 = host h:
+ *   U  used drivers of each host, later overwritten with the result R
+ *   L  extra modules of each host, later the closed loaded set
+ * "host h has loaded everything its loaded modules need" is then one OR of rows
+ * per edge, for all hosts at once, and because the modules are visited in
+ * holder-level order (every holder of v before v) each row is read once per edge
+ * and written once: E x HW word reads in total, no iteration to a fixpoint and no
+ * atomics after the scatter.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "mcx_internal.h"
+
+#define FL_THREADS 256
+
+/* largest h with off[h] <= i, for off[0] = 0 <= i < off[H] */
+__device__ __forceinline__ uint32_t fl_owner(const uint32_t *__restrict__ off, uint32_t H, uint32_t i)
+{
+    uint32_t lo = 0, hi = H;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void fl_set(uint32_t *M, uint32_t HW, uint32_t m, uint32_t h)
+{
+    uint32_t *w = &M[(size_t)m * HW + (h >> 5)];
+    const uint32_t bit = 1u << (h & 31u);
+    if (!(*w & bit))
+        atomicOr(w, bit);
+}
+
+/* one thread per device: U[driver module][host] */
+__global__ void __launch_bounds__(FL_THREADS)
+fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restrict__ a_mod, uint32_t N,
+                const uint32_t *__restrict__ dev_off, uint32_t H, uint32_t V, uint32_t HW, uint32_t *U)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const uint32_t j = first_idx[i];
+    if (j == MCX_NO_MATCH)
+        return;
+    const uint32_t m = a_mod[j];
+    if (m < V)
+        fl_set(U, HW, m, fl_owner(dev_off, H, i));
+}
+
+/* one thread per entry of the hosts' extra-module lists: L[module][host] */
+__global__ void __launch_bounds__(FL_THREADS)
+fl_scatter_extra(const uint32_t *__restrict__ extra_off, const uint32_t *__restrict__ extra_ids, uint32_t X,
+                 uint32_t H, uint32_t V, uint32_t HW, uint32_t *L)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= X)
+        return;
+    const uint32_t m = extra_ids[k];
+    if (m < V)
+        fl_set(L, HW, m, fl_owner(extra_off, H, k));
+}
+
+/*
+ * One holder level.  Thread (v, w): hold = OR over the holders u of v of L[u][w]
+ * (final: u sits in an earlier level), loaded = U | L | hold,
+ *   L[v][w] = loaded
+ *   U[v][w] = eligible[v] ? loaded & ~used & ~hold : 0     (the root bits)
+ */
+__global__ void __launch_bounds__(FL_THREADS)
+fl_level(const uint32_t *__restrict__ order, uint32_t n_rows, const uint32_t *__restrict__ rrowptr,
+         const uint32_t *__restrict__ rcol, const uint8_t *__restrict__ safe_name,
+         const uint8_t *__restrict__ hw_alias, uint32_t HW, uint32_t *U, uint32_t *L)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n_rows * HW)
+        return;
+    const uint32_t v = order[(uint32_t)(t / HW)];
+    const uint32_t w = (uint32_t)(t % HW);
+    uint32_t hold = 0;
+    const uint32_t e1 = rrowptr[v + 1];
+    for (uint32_t e = rrowptr[v]; e < e1; ++e)
+        hold |= L[(size_t)rcol[e] * HW + w];
+    const size_t at = (size_t)v * HW + w;
+    const uint32_t used = U[at];
+    const uint32_t loaded = used | L[at] | hold;
+    L[at] = loaded;
+    U[at] = (safe_name[v] && hw_alias[v]) ? (loaded & ~used & ~hold) : 0u;
+}
+
+/* one thread per host: walk the host's bit column of R in module order */
+__global__ void __launch_bounds__(FL_THREADS)
+fl_count(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, uint32_t *__restrict__ cnt)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H)
+        return;
+    const uint32_t *colw = R + (h >> 5);
+    const uint32_t sh = h & 31u;
+    uint32_t n = 0;
+    for (uint32_t v = 0; v < V; ++v)
+        n += (colw[(size_t)v * HW] >> sh) & 1u;
+    cnt[h] = n;
+}
+
+__global__ void __launch_bounds__(FL_THREADS)
+fl_fill(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW,
+        const uint32_t *__restrict__ root_off, uint32_t *__restrict__ root_ids)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H)
+        return;
+    const uint32_t *colw = R + (h >> 5);
+    const uint32_t sh = h & 31u;
+    uint32_t at = root_off[h];
+    for (uint32_t v = 0; v < V; ++v)
+        if ((colw[(size_t)v * HW] >> sh) & 1u)
+            root_ids[at++] = v;
+}
+
+/* ---- exclusive scan of H counts into H + 1 offsets ------------------------ */
+/* three small kernels: per-block sums, one block over the sums, per-block scan */
+
+#define SCAN_ITEMS 1024u /* per block: 256 threads x 4 */
+
+__device__ __forceinline__ uint32_t fl_block_exclusive(uint32_t mine, uint32_t *total_out)
+{
+    __shared__ uint32_t wsum[FL_THREADS / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d)
+            incl += o;
+    }
+    __syncthreads(); /* wsum may still be read by a previous call */
+    if (lane == 63u)
+        wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < FL_THREADS / 64; ++k) {
+        if (k < wave)
+            base += wsum[k];
+        total += wsum[k];
+    }
+    *total_out = total;
+    return base + incl - mine;
+}
+
+__global__ void __launch_bounds__(FL_THREADS)
+fl_scan_sums(const uint32_t *__restrict__ cnt, uint32_t H, uint32_t *__restrict__ bsum)
+{
+    const uint32_t i0 = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4u;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < 4u; ++k)
+        if (i0 + k < H)
+            mine += cnt[i0 + k];
+    uint32_t total;
+    (void)fl_block_exclusive(mine, &total);
+    if (threadIdx.x == 0)
+        bsum[blockIdx.x] = total;
+}
+
+/* single block: bsum[b] becomes the sum of the blocks before b; 64-bit grand total */
+__global__ void __launch_bounds__(FL_THREADS)
+fl_scan_top(uint32_t *bsum, uint32_t nb, unsigned long long *grand)
+{
+    unsigned long long carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += FL_THREADS) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t mine = b < nb ? bsum[b] : 0u;
+        uint32_t total;
+        const uint32_t ex = fl_block_exclusive(mine, &total);
+        if (b < nb)
+            bsum[b] = (uint32_t)carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0)
+        *grand = carry;
+}
+
+__global__ void __launch_bounds__(FL_THREADS)
+fl_scan_apply(const uint32_t *__restrict__ cnt, uint32_t H, const uint32_t *__restrict__ bsum,
+              uint32_t *__restrict__ off)
+{
+    const uint32_t i0 = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4u;
+    uint32_t c[4], mine = 0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        c[k] = i0 + k < H ? cnt[i0 + k] : 0u;
+        mine += c[k];
+    }
+    uint32_t total;
+    uint32_t at = bsum[blockIdx.x] + fl_block_exclusive(mine, &total);
+    for (uint32_t k = 0; k < 4u; ++k) {
+        if (i0 + k < H)
+            off[i0 + k] = at;
+        at += c[k];
+    }
+    /* off[H]: the thread that owns the last count also writes the end */
+    if (H - 1u >= i0 && H - 1u < i0 + 4u)
+        off[H] = at;
+}
+
+/* ------------------------------------------------------------------------- */
+/* C ABI                                                                      */
+/* ------------------------------------------------------------------------- */
+
+static int fleet_scratch(mcx_ctx *ctx, size_t bytes, void **out)
+{
+    if (ctx->fleet_bytes < bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_fleet);
+        ctx->d_fleet = nullptr;
+        ctx->fleet_bytes = 0;
+        if (hipMalloc(&ctx->d_fleet, bytes) != hipSuccess) {
+            ctx->err = "fleet scratch of " + std::to_string(bytes) +
+                       " bytes does not fit the device: split the fleet into groups of hosts";
+            return MCX_E_NOMEM;
+        }
+        ctx->fleet_bytes = bytes;
+    }
+    *out = ctx->d_fleet;
+    return MCX_OK;
+}
+
+static size_t up256(size_t x)
+{
+    return (x + 255) & ~(size_t)255;
+}
+
+extern "C" {
+
+int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
+                        uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                        const void *d_safe_name, void *d_root_off, void *d_root_ids, uint64_t cap,
+                        uint64_t *total_out)
+{
+    if (!ctx || !d_s_off || !d_dev_off || !d_extra_off || !d_root_off || !total_out || (X && !d_extra_ids) ||
+        (cap && !d_root_ids))
+        return MCX_E_BAD_ARG;
+    if (!ctx->table_loaded || !ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    *total_out = 0;
+    const uint32_t V = ctx->V;
+    if (V && !d_safe_name)
+        return MCX_E_BAD_ARG;
+    if (ctx->lvl_ptr.empty()) {
+        ctx->err = "the dependency graph has a cycle: no load order, no fleet pipeline";
+        return MCX_E_BAD_ARG;
+    }
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    if (H == 0) {
+        HIPCHK(ctx, hipMemsetAsync(d_root_off, 0, 4, ctx->stream));
+        return MCX_OK;
+    }
+    const uint32_t HW = (H + 31u) / 32u;
+    const uint32_t nb = (H + SCAN_ITEMS - 1u) / SCAN_ITEMS;
+    /* scratch: U, L, first_idx, count, per-host counts, block sums, hw flags, total */
+    const size_t mat = up256(4 * (size_t)(V ? V : 1) * HW);
+    const size_t o_first = 2 * mat, o_count = o_first + up256(4 * (size_t)(N ? N : 1));
+    const size_t o_cnt = o_count + up256(4 * (size_t)(N ? N : 1)), o_bsum = o_cnt + up256(4 * (size_t)H);
+    const size_t o_hw = o_bsum + up256(4 * (size_t)nb), o_total = o_hw + up256(V ? V : 1);
+    void *base;
+    int rc = fleet_scratch(ctx, o_total + 256, &base);
+    if (rc != MCX_OK)
+        return rc;
+    uint32_t *U = (uint32_t *)base, *L = (uint32_t *)((char *)base + mat);
+    uint32_t *d_first = (uint32_t *)((char *)base + o_first), *d_count = (uint32_t *)((char *)base + o_count);
+    uint32_t *d_cnt = (uint32_t *)((char *)base + o_cnt), *d_bsum = (uint32_t *)((char *)base + o_bsum);
+    uint8_t *d_hw = (uint8_t *)base + o_hw;
+    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
+
+    HIPCHK(ctx, hipMemsetAsync(base, 0, 2 * mat, ctx->stream));
+    if ((rc = mcx_k1_hw_flags_dev(ctx, V, d_hw)) != MCX_OK)
+        return rc;
+    if (N) {
+        if ((rc = mcx_alias_match_dev(ctx, d_S, d_s_off, N, d_first, d_count)) != MCX_OK)
+            return rc;
+        fl_scatter_used<<<(N + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+            d_first, ctx->d_amod, N, (const uint32_t *)d_dev_off, H, V, HW, U);
+    }
+    if (X)
+        fl_scatter_extra<<<(X + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+            (const uint32_t *)d_extra_off, (const uint32_t *)d_extra_ids, X, H, V, HW, L);
+    for (size_t k = 0; k + 1 < ctx->lvl_ptr.size(); ++k) {
+        const uint32_t r0 = ctx->lvl_ptr[k], n_rows = ctx->lvl_ptr[k + 1] - r0;
+        const uint64_t threads = (uint64_t)n_rows * HW;
+        const uint64_t blocks = (threads + FL_THREADS - 1) / FL_THREADS;
+        if (blocks > 0x7FFFFFFFull) {
+            ctx->err = "fleet too large for one launch: split the fleet into groups of hosts";
+            return MCX_E_TOO_LARGE;
+        }
+        fl_level<<<(uint32_t)blocks, FL_THREADS, 0, ctx->stream>>>(ctx->d_lvl_order + r0, n_rows, ctx->d_rrowptr,
+                                                                  ctx->d_rcol, (const uint8_t *)d_safe_name, d_hw,
+                                                                  HW, U, L);
+    }
+    fl_count<<<(H + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_cnt);
+    fl_scan_sums<<<nb, FL_THREADS, 0, ctx->stream>>>(d_cnt, H, d_bsum);
+    fl_scan_top<<<1, FL_THREADS, 0, ctx->stream>>>(d_bsum, nb, d_total);
+    fl_scan_apply<<<nb, FL_THREADS, 0, ctx->stream>>>(d_cnt, H, d_bsum, (uint32_t *)d_root_off);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
+    HIPCHK(ctx, hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *total_out = *h_total;
+    if (*h_total > 0xFFFFFFFFull) {
+        ctx->err = "more than 2^32 - 1 listed modules: split the fleet into groups of hosts";
+        return MCX_E_TOO_LARGE;
+    }
+    if (*h_total > cap) {
+        ctx->err = "root_ids too small: " + std::to_string(*h_total) + " entries needed";
+        return MCX_E_TOO_LARGE;
+    }
+    if (*h_total)
+        fl_fill<<<(H + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+            U, V, H, HW, (const uint32_t *)d_root_off, (uint32_t *)d_root_ids);
+    HIPCHK(ctx, hipGetLastError());
+    return MCX_OK;
+}
+
+int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
+                    uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids, const uint8_t *safe_name,
+                    uint32_t *root_off, uint32_t *root_ids, uint64_t cap, uint64_t *total_out)
+{
+    if (!ctx || !s_off || !dev_off || !extra_off || !root_off || !total_out)
+        return MCX_E_BAD_ARG;
+    if (!ctx->table_loaded || !ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    if (ctx->norm_dash) {
+        ctx->err = "a table loaded with MCX_TABLE_NORMALIZE_DASH cannot be used by the fleet pipeline";
+        return MCX_E_BAD_ARG;
+    }
+    if (dev_off[0] != 0 || dev_off[H] != N || extra_off[0] != 0) {
+        ctx->err = "dev_off must run from 0 to N and extra_off from 0";
+        return MCX_E_BAD_ARG;
+    }
+    for (uint32_t h = 0; h < H; ++h)
+        if (dev_off[h + 1] < dev_off[h] || extra_off[h + 1] < extra_off[h]) {
+            ctx->err = "host offsets not monotonic";
+            return MCX_E_BAD_ARG;
+        }
+    for (uint32_t i = 0; i < N; ++i)
+        if (s_off[i + 1] < s_off[i]) {
+            ctx->err = "s_off not monotonic";
+            return MCX_E_BAD_ARG;
+        }
+    const uint32_t X = extra_off[H];
+    if ((X && !extra_ids) || (N && s_off[N] && !S) || (ctx->V && !safe_name))
+        return MCX_E_BAD_ARG;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    const uint32_t V = ctx->V;
+    /* one staging allocation for the inputs and outputs */
+    const size_t sb = s_off[N];
+    const size_t o_soff = up256(sb ? sb : 1), o_dev = o_soff + up256(4 * ((size_t)N + 1));
+    const size_t o_xoff = o_dev + up256(4 * ((size_t)H + 1)), o_xid = o_xoff + up256(4 * ((size_t)H + 1));
+    const size_t o_safe = o_xid + up256(4 * (size_t)(X ? X : 1)), o_roff = o_safe + up256(V ? V : 1);
+    const size_t o_rid = o_roff + up256(4 * ((size_t)H + 1));
+    const size_t bytes = o_rid + up256(4 * (size_t)(cap ? cap : 1));
+    char *d = nullptr;
+    if (hipMalloc((void **)&d, bytes) != hipSuccess) {
+        ctx->err = "hipMalloc of the staging buffers failed";
+        return MCX_E_NOMEM;
+    }
+    hipError_t e = hipSuccess;
+    if (sb)
+        e = hipMemcpyAsync(d, S, sb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d + o_soff, s_off, 4 * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d + o_dev, dev_off, 4 * ((size_t)H + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d + o_xoff, extra_off, 4 * ((size_t)H + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && X)
+        e = hipMemcpyAsync(d + o_xid, extra_ids, 4 * (size_t)X, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && V)
+        e = hipMemcpyAsync(d + o_safe, safe_name, V, hipMemcpyHostToDevice, ctx->stream);
+    int rc = MCX_OK;
+    if (e != hipSuccess) {
+        ctx->err = std::string("copy in: ") + hipGetErrorString(e);
+        rc = MCX_E_HIP;
+    }
+    if (rc == MCX_OK)
+        rc = mcx_fleet_roots_dev(ctx, d, d + o_soff, N, d + o_dev, H, d + o_xoff, d + o_xid, X, d + o_safe,
+                                 d + o_roff, cap ? d + o_rid : nullptr, cap, total_out);
+    /* the offsets are valid even when root_ids was too small: a caller may
+     * size the list from them and call again */
+    if (rc == MCX_OK || (rc == MCX_E_TOO_LARGE && *total_out <= 0xFFFFFFFFull && *total_out > cap)) {
+        e = hipMemcpyAsync(root_off, d + o_roff, 4 * ((size_t)H + 1), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == MCX_OK && *total_out)
+            e = hipMemcpyAsync(root_ids, d + o_rid, 4 * (size_t)*total_out, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->err = std::string("copy back: ") + hipGetErrorString(e);
+            rc = MCX_E_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+} /* extern "C" */

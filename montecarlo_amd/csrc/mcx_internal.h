@@ -9,6 +9,7 @@
 
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/mcx.h"
 #include "mcx_prog.h"
@@ -51,6 +52,17 @@ struct mcx_ctx {
     uint32_t *d_queue[2] = {nullptr, nullptr}; /* BFS frontiers, V entries each */
     uint32_t *d_bfs = nullptr;     /* per-level frontier sizes + edge counter  */
     uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */
+
+    /* holder levels of the graph (fleet pipeline): level 0 = modules nobody
+     * needs, level k = modules whose holders all sit in levels < k.  lvl_order
+     * lists the modules level by level, lvl_ptr[k]..lvl_ptr[k+1] is level k.
+     * Empty lvl_ptr: the graph has a cycle and has no such order. */
+    uint32_t *d_lvl_order = nullptr;
+    std::vector<uint32_t> lvl_ptr;
+
+    /* scratch of the fleet pipeline, grown on demand, freed with the context */
+    void *d_fleet = nullptr;
+    size_t fleet_bytes = 0;
 };
 
 #define HIPCHK(ctx, call)                                                              \
@@ -79,6 +91,8 @@ static int mcx_dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 }
 
 void mcx_free_table(mcx_ctx *ctx);
+/* d_hw[m] = 1 iff module m < n_modules owns a hardware-bus alias; enqueues */
+int mcx_k1_hw_flags_dev(mcx_ctx *ctx, uint32_t n_modules, uint8_t *d_hw);
 void mcx_free_graph(mcx_ctx *ctx);
 
 #endif /* MCX_INTERNAL_H */

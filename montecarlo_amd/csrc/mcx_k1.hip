@@ -694,14 +694,15 @@ int mcx_alias_hw_flags(mcx_ctx *ctx, uint32_t n_modules, uint8_t *hw_alias)
         return MCX_E_HIP;
     uint8_t *d_hw = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d_hw, n_modules));
-    (void)hipMemsetAsync(d_hw, 0, n_modules, ctx->stream);
-    if (ctx->P)
-        k1_hw_flags<<<(ctx->P + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_hwtag, ctx->d_amod, ctx->P, n_modules,
-                                                               d_hw);
-    hipError_t e = hipMemcpyAsync(hw_alias, d_hw, n_modules, hipMemcpyDeviceToHost, ctx->stream);
+    int rc = mcx_k1_hw_flags_dev(ctx, n_modules, d_hw);
+    hipError_t e = hipSuccess;
+    if (rc == MCX_OK)
+        e = hipMemcpyAsync(hw_alias, d_hw, n_modules, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_hw);
+    if (rc != MCX_OK)
+        return rc;
     if (e != hipSuccess) {
         ctx->err = hipGetErrorString(e);
         return MCX_E_HIP;
@@ -710,3 +711,15 @@ int mcx_alias_hw_flags(mcx_ctx *ctx, uint32_t n_modules, uint8_t *hw_alias)
 }
 
 } /* extern "C" */
+
+int mcx_k1_hw_flags_dev(mcx_ctx *ctx, uint32_t n_modules, uint8_t *d_hw)
+{
+    if (n_modules == 0)
+        return MCX_OK;
+    HIPCHK(ctx, hipMemsetAsync(d_hw, 0, n_modules, ctx->stream));
+    if (ctx->P)
+        k1_hw_flags<<<(ctx->P + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_hwtag, ctx->d_amod, ctx->P, n_modules,
+                                                               d_hw);
+    HIPCHK(ctx, hipGetLastError());
+    return MCX_OK;
+}

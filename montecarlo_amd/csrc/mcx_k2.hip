@@ -302,6 +302,44 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         part.push_back(end);
         r = end;
     }
+    /* holder levels (Kahn over "u needs v": v follows all of its holders);
+     * a graph with a cycle has none and only the fleet pipeline minds */
+    std::vector<uint32_t> order, lvl_ptr;
+    {
+        std::vector<uint32_t> waiting((size_t)V), level((size_t)V, 0);
+        order.reserve(V);
+        for (uint32_t v = 0; v < V; ++v) {
+            waiting[v] = rrow[(size_t)v + 1] - rrow[v];
+            if (waiting[v] == 0)
+                order.push_back(v);
+        }
+        for (size_t q = 0; q < order.size(); ++q) {
+            const uint32_t u = order[q];
+            for (uint32_t k = rowptr[u]; k < rowptr[u + 1]; ++k) {
+                const uint32_t v = col[k];
+                if (level[v] < level[u] + 1u)
+                    level[v] = level[u] + 1u;
+                if (--waiting[v] == 0)
+                    order.push_back(v);
+            }
+        }
+        if (order.size() == (size_t)V) {
+            /* Kahn's queue is not sorted by level: bucket it */
+            uint32_t nl = 0;
+            for (uint32_t v = 0; v < V; ++v)
+                nl = level[v] + 1u > nl ? level[v] + 1u : nl;
+            lvl_ptr.assign((size_t)nl + 1, 0);
+            for (uint32_t v = 0; v < V; ++v)
+                lvl_ptr[(size_t)level[v] + 1]++;
+            for (uint32_t k = 0; k < nl; ++k)
+                lvl_ptr[(size_t)k + 1] += lvl_ptr[k];
+            std::vector<uint32_t> at(lvl_ptr.begin(), lvl_ptr.end() - 1);
+            for (uint32_t v = 0; v < V; ++v)
+                order[at[level[v]]++] = v;
+        } else {
+            order.clear();
+        }
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     mcx_free_graph(ctx);
     int rc;
@@ -309,7 +347,8 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         (rc = mcx_dev_upload(ctx, &ctx->d_col, col, (size_t)E)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_rrowptr, rrow.data(), (size_t)V + 1)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_rcol, rcol.data(), (size_t)E)) != 0 ||
-        (rc = mcx_dev_upload(ctx, &ctx->d_part, part.data(), part.size())) != 0) {
+        (rc = mcx_dev_upload(ctx, &ctx->d_part, part.data(), part.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_lvl_order, order.data(), order.size())) != 0) {
         mcx_free_graph(ctx);
         return rc;
     }
@@ -325,6 +364,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     ctx->V = V;
     ctx->E = E;
     ctx->n_part = (uint32_t)part.size() - 1u;
+    ctx->lvl_ptr = lvl_ptr;
     ctx->graph_loaded = true;
     return MCX_OK;
 }

@@ -49,7 +49,7 @@ static uint32_t rng_below(rng_t *r, uint32_t n)
     return (uint32_t)(rng_next(r) % n);
 }
 
-enum { K_MODULE = 1, K_PATTERN = 2, K_STRING = 3, K_VERTEX = 4, K_FLAGS = 5, K_SEEDSET = 6, K_NAME = 7 };
+enum { K_MODULE = 1, K_PATTERN = 2, K_STRING = 3, K_VERTEX = 4, K_FLAGS = 5, K_SEEDSET = 6, K_NAME = 7, K_HOST = 8 };
 
 /* ---- vendors: 512 ids, Zipf(1) popularity -------------------------------- */
 
@@ -594,5 +594,37 @@ uint64_t mcxs_module_names(uint64_t seed, uint32_t m0, uint32_t m1, char *buf, u
     }
     if (off)
         off[m1 - m0] = (uint32_t)w;
+    return w;
+}
+
+/*
+ * A fleet of hosts for the inventory pipeline.  Host h has
+ * mean_dev/2 + (draw below mean_dev + 1) devices (the strings of the batch are
+ * dealt out to the hosts in order) and up to max_extra extra loaded modules
+ * drawn uniformly from [0, V) (duplicates possible, as in a list collected
+ * from several sources).  dev_cnt and extra_cnt receive h1 - h0 counts;
+ * extra_ids (may be NULL to count) the lists back to back.  Returns the
+ * number of extra entries.
+ */
+uint64_t mcxs_fleet_hosts(uint64_t seed, uint32_t V, uint64_t h0, uint64_t h1, uint32_t mean_dev,
+                          uint32_t max_extra, uint32_t *dev_cnt, uint32_t *extra_cnt, uint32_t *extra_ids,
+                          uint64_t cap)
+{
+    uint64_t w = 0;
+    for (uint64_t h = h0; h < h1; ++h) {
+        rng_t r = rng_stream(seed, K_HOST, h);
+        uint32_t nd = mean_dev / 2 + rng_below(&r, mean_dev + 1);
+        uint32_t nx = V ? rng_below(&r, max_extra + 1) : 0;
+        if (dev_cnt)
+            dev_cnt[h - h0] = nd;
+        if (extra_cnt)
+            extra_cnt[h - h0] = nx;
+        for (uint32_t k = 0; k < nx; ++k) {
+            uint32_t m = rng_below(&r, V);
+            if (extra_ids && w < cap)
+                extra_ids[w] = m;
+            ++w;
+        }
+    }
     return w;
 }

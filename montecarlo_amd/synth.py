@@ -34,6 +34,8 @@ def _lib():
         lib.mcxs_seed_bitmap.argtypes = [u64, u32, u32, _vp, _vp]
         lib.mcxs_module_names.restype = u64
         lib.mcxs_module_names.argtypes = [u64, u32, u32, _vp, u64, _vp]
+        lib.mcxs_fleet_hosts.restype = u64
+        lib.mcxs_fleet_hosts.argtypes = [u64, u32, u64, u64, u32, u32, _vp, _vp, _vp, u64]
         _LIB = lib
     return _LIB
 
@@ -107,3 +109,28 @@ def module_names(seed, V, m0=0, m1=None):
     lib.mcxs_module_names(seed, m0, m1, _p(buf), nbytes, _p(off))
     raw = buf[:nbytes].tobytes()
     return [raw[off[k]:off[k + 1]].decode() for k in range(m1 - m0)]
+
+
+def module_names_packed(seed, V):
+    """all V module names as (arena uint8, offsets uint32[V+1])"""
+    lib = _lib()
+    off = np.zeros(V + 1, dtype=np.uint32)
+    nbytes = lib.mcxs_module_names(seed, 0, V, None, 0, None)
+    buf = np.zeros(max(nbytes, 1), dtype=np.uint8)
+    lib.mcxs_module_names(seed, 0, V, _p(buf), nbytes, _p(off))
+    return buf[:nbytes], off
+
+
+def fleet_hosts(seed, V, H, mean_dev=100, max_extra=8, h0=0, h1=None):
+    """hosts h0..h1 of an H-host fleet -> (dev_cnt, extra_off, extra_ids)"""
+    h1 = H if h1 is None else h1
+    lib = _lib()
+    n = h1 - h0
+    dev_cnt = np.zeros(max(n, 1), dtype=np.uint32)
+    extra_cnt = np.zeros(max(n, 1), dtype=np.uint32)
+    X = lib.mcxs_fleet_hosts(seed, V, h0, h1, mean_dev, max_extra, _p(dev_cnt), _p(extra_cnt), None, 0)
+    ids = np.zeros(max(X, 1), dtype=np.uint32)
+    lib.mcxs_fleet_hosts(seed, V, h0, h1, mean_dev, max_extra, None, None, _p(ids), X)
+    extra_off = np.zeros(n + 1, dtype=np.uint32)
+    extra_off[1:] = np.cumsum(extra_cnt[:n], dtype=np.uint64).astype(np.uint32)
+    return dev_cnt[:n], extra_off, ids[:X]

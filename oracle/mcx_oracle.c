@@ -363,3 +363,89 @@ int orc_has_hw_alias(const char *aliases)
     }
     return 0;
 }
+
+/* ---- fleet inventory: the dashboard's module list, one host after another --
+ * For every host the loop of reference desktop/ui.py:1565-1599 is restated over
+ * tables instead of sysfs:
+ *   used     drivers bound to the host's devices (ui.py builds used_drivers
+ *            from mc_list_all_usb_devices records); here the module a device's
+ *            modalias resolves to (driver_mod[i], 0xFFFFFFFF = none),
+ *   loaded   /proc/modules of the host: the used drivers and the host's extra
+ *            modules, closed under "needs" (loading a module loads what it
+ *            needs, so /proc/modules is always closed),
+ *   holders  /sys/module/<v>/holders: loaded modules that need v
+ *            (libmontecarlo.c:446-473).
+ * A module is listed when it is loaded, is not a used driver (ui.py:1567),
+ * passes is_safe_module - name stages safe_name[v], hardware-alias stage
+ * hw_alias[v] (ui.py:1571, 1391-1562) - and has no holders (ui.py:1575-1577).
+ * Output: root_off[h]..root_off[h+1] index root_ids, ascending module ids per
+ * host.  root_ids may be NULL to count only.  Returns the total.
+ */
+static int orc_cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return (x > y) - (x < y);
+}
+
+uint64_t orc_fleet_roots(const uint32_t *rowptr, const uint32_t *col, uint32_t V,
+                         const uint32_t *driver_mod, const uint32_t *dev_off, uint32_t H,
+                         const uint32_t *extra_off, const uint32_t *extra_ids,
+                         const uint8_t *safe_name, const uint8_t *hw_alias,
+                         uint32_t *root_off, uint32_t *root_ids)
+{
+    /* per-host marks are stamped with h + 1 so nothing is cleared between hosts */
+    uint32_t *used = (uint32_t *)calloc(V ? V : 1, sizeof(uint32_t));
+    uint32_t *loaded = (uint32_t *)calloc(V ? V : 1, sizeof(uint32_t));
+    uint32_t *held = (uint32_t *)calloc(V ? V : 1, sizeof(uint32_t));
+    uint32_t *list = (uint32_t *)malloc(sizeof(uint32_t) * (V ? V : 1));
+    uint64_t total = 0;
+    for (uint32_t h = 0; h < H; ++h) {
+        const uint32_t stamp = h + 1;
+        uint32_t n = 0;
+        for (uint32_t i = dev_off[h]; i < dev_off[h + 1]; ++i) {
+            uint32_t m = driver_mod[i];
+            if (m >= V)
+                continue;
+            used[m] = stamp;
+            if (loaded[m] != stamp) {
+                loaded[m] = stamp;
+                list[n++] = m;
+            }
+        }
+        for (uint32_t k = extra_off[h]; k < extra_off[h + 1]; ++k) {
+            uint32_t m = extra_ids[k];
+            if (m < V && loaded[m] != stamp) {
+                loaded[m] = stamp;
+                list[n++] = m;
+            }
+        }
+        /* close under "needs"; list doubles as the work queue */
+        for (uint32_t q = 0; q < n; ++q) {
+            uint32_t u = list[q];
+            for (uint32_t k = rowptr[u]; k < rowptr[u + 1]; ++k) {
+                uint32_t v = col[k];
+                held[v] = stamp;
+                if (loaded[v] != stamp) {
+                    loaded[v] = stamp;
+                    list[n++] = v;
+                }
+            }
+        }
+        root_off[h] = (uint32_t)total;
+        qsort(list, n, sizeof(uint32_t), orc_cmp_u32);
+        for (uint32_t q = 0; q < n; ++q) {
+            uint32_t v = list[q];
+            if (used[v] == stamp || !safe_name[v] || !hw_alias[v] || held[v] == stamp)
+                continue;
+            if (root_ids)
+                root_ids[total] = v;
+            ++total;
+        }
+    }
+    root_off[H] = (uint32_t)total;
+    free(used);
+    free(loaded);
+    free(held);
+    free(list);
+    return total;
+}

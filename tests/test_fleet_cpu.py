@@ -1,0 +1,107 @@
+"""CPU tests around the fleet pipeline: the product's module-name filter (host
+code, no device needed) against the golden table and the oracle, and the fleet
+oracle against a set-based restatement in Python and a hand-made case."""
+import json
+import os
+
+import numpy as np
+
+from montecarlo_amd import safe_module_names, synth
+from montecarlo_amd.binding import load_library
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NO_MATCH = 0xFFFFFFFF
+
+
+def test_name_filter_golden(oracle_mod):
+    g = json.load(open(os.path.join(GOLDEN, "safe_names.json")))
+    import ctypes
+
+    lib = load_library()
+    nc, npf = ctypes.c_uint32(), ctypes.c_uint32()
+    assert lib.mcx_safe_table_sizes(ctypes.byref(nc), ctypes.byref(npf)) == 0
+    assert (nc.value, npf.value) == (g["n_core"], g["n_prefix"]) == (113, 56)
+    names = [c[0] for c in g["cases"]]
+    want = np.array([c[1] for c in g["cases"]], dtype=np.uint8)
+    got = safe_module_names(names)
+    assert np.array_equal(got, want)
+    # every core name and every prefix, bare and extended, against the oracle
+    probe = []
+    for c in g["core"]:
+        probe += [c, c + "x", c[:-1], c.upper(), "_" + c]
+    for p in g["prefixes"]:
+        probe += [p, p + "zz", p[:-1], "x" + p]
+    probe += ["", "e1000", "ac", "a", "st", "s", "sg3", "snd", "snd_", "snd-hda", "hid", "hidp", "hid_", "hi"]
+    got = safe_module_names(probe)
+    want = np.array([oracle_mod.safe_name(n) for n in probe], dtype=np.uint8)
+    assert np.array_equal(got, want)
+
+
+def test_name_filter_synthetic_names(oracle_mod):
+    names = synth.module_names(11, 5000)
+    got = safe_module_names(names)
+    want = np.array([oracle_mod.safe_name(n) for n in names], dtype=np.uint8)
+    assert np.array_equal(got, want)
+    assert 0 < got.sum() < len(names)
+    arena, off = synth.module_names_packed(11, 5000)
+    assert [bytes(arena[off[k]:off[k + 1]]).decode() for k in range(0, 5000, 499)] == names[0:5000:499]
+
+
+def fleet_by_sets(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe, hw):
+    """the dashboard loop with Python sets, one host at a time"""
+    V = len(rowptr) - 1
+    out_off, out = [0], []
+    for h in range(len(dev_off) - 1):
+        used = {int(m) for m in driver_mod[dev_off[h]:dev_off[h + 1]] if m < V}
+        loaded = set(used) | {int(m) for m in extra_ids[extra_off[h]:extra_off[h + 1]] if m < V}
+        work = list(loaded)
+        while work:
+            u = work.pop()
+            for v in col[rowptr[u]:rowptr[u + 1]]:
+                if int(v) not in loaded:
+                    loaded.add(int(v))
+                    work.append(int(v))
+        held = {int(v) for u in loaded for v in col[rowptr[u]:rowptr[u + 1]]}
+        roots = sorted(m for m in loaded if m not in used and safe[m] and hw[m] and m not in held)
+        out += roots
+        out_off.append(len(out))
+    return np.array(out_off, dtype=np.uint32), np.array(out, dtype=np.uint32)
+
+
+def test_fleet_oracle_hand_case(oracle_mod):
+    # 0 -> 1 -> 2, 3 -> 2, 4 alone, 5 -> 4 ("u needs v")
+    rowptr = np.array([0, 1, 2, 2, 3, 3, 4], dtype=np.uint32)
+    col = np.array([1, 2, 2, 4], dtype=np.uint32)
+    safe = np.array([1, 1, 1, 1, 1, 0], dtype=np.uint8)
+    hw = np.array([1, 1, 1, 1, 0, 1], dtype=np.uint8)
+    # host 0: device driven by 1, extra 3     -> loaded {1,2,3}; 1 used, 2 held, 3 listed
+    # host 1: no device, extras 0 and 5       -> loaded {0,1,2,5,4}; 0 listed, 5 unsafe name, 4 held
+    # host 2: device driven by 4, unmatched   -> loaded {4}, used: nothing listed
+    # host 3: nothing at all
+    # host 4: extra 4 (no hardware alias), extra 9 (out of range) -> nothing listed
+    driver_mod = np.array([1, 4, NO_MATCH], dtype=np.uint32)
+    dev_off = np.array([0, 1, 1, 3, 3, 3], dtype=np.uint32)
+    extra_off = np.array([0, 1, 3, 3, 3, 5], dtype=np.uint32)
+    extra_ids = np.array([3, 0, 5, 4, 9], dtype=np.uint32)
+    off, ids = oracle_mod.fleet_roots(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe, hw)
+    assert off.tolist() == [0, 1, 2, 2, 2, 2]
+    assert ids.tolist() == [3, 0]
+
+
+def test_fleet_oracle_vs_sets(oracle_mod):
+    rng = np.random.default_rng(5)
+    for V, H in [(40, 30), (300, 64), (1, 3)]:
+        rowptr, col = synth.dep_graph(V + 1, V, 3)
+        dev_cnt, extra_off, extra_ids = synth.fleet_hosts(9, V, H, mean_dev=6, max_extra=3)
+        dev_off = np.zeros(H + 1, dtype=np.uint32)
+        dev_off[1:] = np.cumsum(dev_cnt)
+        N = int(dev_off[H])
+        driver_mod = rng.integers(0, V + 2, size=max(N, 1)).astype(np.uint32)
+        driver_mod[rng.random(len(driver_mod)) < 0.2] = NO_MATCH
+        safe = (rng.random(V) < 0.7).astype(np.uint8)
+        hw = (rng.random(V) < 0.8).astype(np.uint8)
+        off, ids = oracle_mod.fleet_roots(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe, hw)
+        w_off, w_ids = fleet_by_sets(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe, hw)
+        assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
+        if V > 1:
+            assert len(ids) > 0

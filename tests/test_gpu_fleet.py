@@ -1,0 +1,154 @@
+"""GPU parity of the fleet pipeline (mcx_fleet_roots through the C ABI): alias
+match -> used drivers -> loaded set -> holders -> root filter on the device,
+against the CPU oracle's per-host loop on the same seeded fleets.  Bit-exact."""
+import numpy as np
+import pytest
+
+from montecarlo_amd import McxError, safe_module_names, synth
+from montecarlo_amd.binding import pack_strings
+
+pytestmark = pytest.mark.gpu
+NO_MATCH = 0xFFFFFFFF
+
+
+def make_fleet(seed, P, H, mean_dev, max_extra, mean_deg=4):
+    A, a_off, a_mod = synth.alias_table(seed, P)
+    V = synth.alias_modules(P)
+    rowptr, col = synth.dep_graph(seed + 1, V, mean_deg)
+    dev_cnt, extra_off, extra_ids = synth.fleet_hosts(seed + 2, V, H, mean_dev, max_extra)
+    dev_off = np.zeros(H + 1, dtype=np.uint32)
+    dev_off[1:] = np.cumsum(dev_cnt)
+    N = int(dev_off[H])
+    S, s_off = synth.modalias_strings(seed + 3, P, N)
+    safe = safe_module_names(synth.module_names(seed + 4, V))
+    return dict(A=A, a_off=a_off, a_mod=a_mod, V=V, rowptr=rowptr, col=col, dev_off=dev_off,
+                extra_off=extra_off, extra_ids=extra_ids, S=S, s_off=s_off, safe=safe, N=N, H=H)
+
+
+def oracle_fleet(oracle_mod, ctx, f, use_twin=False):
+    first, _ = oracle_mod.alias_match(f["A"], f["a_off"], f["S"], f["s_off"], use_twin=use_twin)
+    driver = np.where(first != NO_MATCH, f["a_mod"][np.minimum(first, len(f["a_mod"]) - 1)], NO_MATCH)
+    hw = ctx.alias_hw_flags(f["V"])  # checked on its own against the reference's rule in test_k1_hw_flags
+    return oracle_mod.fleet_roots(f["rowptr"], f["col"], driver.astype(np.uint32), f["dev_off"], f["extra_off"],
+                                  f["extra_ids"], f["safe"], hw)
+
+
+def run_fleet(ctx, f, cap=None):
+    ctx.alias_table_load(f["A"], f["a_off"], f["a_mod"])
+    ctx.dep_graph_load(f["rowptr"], f["col"])
+    return ctx.fleet_roots(f["S"], f["s_off"], f["dev_off"], f["extra_off"], f["extra_ids"], f["safe"], cap=cap)
+
+
+@pytest.mark.parametrize("seed,P,H,mean_dev,max_extra", [(21, 3000, 257, 12, 4), (22, 500, 33, 3, 2),
+                                                         (23, 2000, 1, 40, 6), (24, 800, 1025, 2, 1)])
+def test_fleet_vs_oracle(gpu_ctx, oracle_mod, seed, P, H, mean_dev, max_extra):
+    f = make_fleet(seed, P, H, mean_dev, max_extra)
+    off, ids = run_fleet(gpu_ctx, f)
+    w_off, w_ids = oracle_fleet(oracle_mod, gpu_ctx, f)
+    assert np.array_equal(off, w_off)
+    assert np.array_equal(ids, w_ids)
+    assert len(ids) > 0
+
+
+def test_fleet_edge_cases(gpu_ctx, oracle_mod):
+    f = make_fleet(31, 1000, 40, 5, 3)
+    gpu_ctx.alias_table_load(f["A"], f["a_off"], f["a_mod"])
+    gpu_ctx.dep_graph_load(f["rowptr"], f["col"])
+    H = f["H"]
+    # no hosts
+    off, ids = gpu_ctx.fleet_roots(np.zeros(0, np.uint8), np.zeros(1, np.uint32), np.zeros(1, np.uint32),
+                                   np.zeros(1, np.uint32), np.zeros(0, np.uint32), f["safe"])
+    assert off.tolist() == [0] and len(ids) == 0
+    # hosts without devices: extras only
+    zero_dev = np.zeros(H + 1, dtype=np.uint32)
+    off, ids = gpu_ctx.fleet_roots(np.zeros(0, np.uint8), np.zeros(1, np.uint32), zero_dev, f["extra_off"],
+                                   f["extra_ids"], f["safe"])
+    hw = gpu_ctx.alias_hw_flags(f["V"])
+    w_off, w_ids = oracle_mod.fleet_roots(f["rowptr"], f["col"], np.zeros(0, np.uint32), zero_dev, f["extra_off"],
+                                          f["extra_ids"], f["safe"], hw)
+    assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
+    # hosts without extras: every loaded module is a used driver or held by one -> nothing is listed
+    zero_x = np.zeros(H + 1, dtype=np.uint32)
+    off, ids = gpu_ctx.fleet_roots(f["S"], f["s_off"], f["dev_off"], zero_x, np.zeros(0, np.uint32), f["safe"])
+    assert len(ids) == 0 and not off.any()
+    # an output list that is too small: error, total and offsets still reported
+    w_off, w_ids = oracle_fleet(oracle_mod, gpu_ctx, f)
+    assert len(w_ids) > 1
+    with pytest.raises(McxError) as e:
+        gpu_ctx.fleet_roots(f["S"], f["s_off"], f["dev_off"], f["extra_off"], f["extra_ids"], f["safe"], cap=1)
+    assert e.value.rc == -6
+    off, ids = gpu_ctx.fleet_roots(f["S"], f["s_off"], f["dev_off"], f["extra_off"], f["extra_ids"], f["safe"],
+                                   cap=len(w_ids))
+    assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
+    # a graph with a cycle has no load order
+    gpu_ctx.dep_graph_load(np.array([0, 1, 2], np.uint32), np.array([1, 0], np.uint32))
+    with pytest.raises(McxError) as e:
+        gpu_ctx.fleet_roots(np.zeros(0, np.uint8), np.zeros(1, np.uint32), np.zeros(2, np.uint32),
+                            np.zeros(2, np.uint32), np.zeros(0, np.uint32), np.ones(2, np.uint8))
+    assert e.value.rc == -2
+
+
+def test_fleet_hand_case(gpu_ctx, oracle_mod):
+    """the hand-made fleet of the CPU suite, with real patterns in front of it"""
+    pats = [b"pci:v00008086d00001234*", b"usb:v1D6Bp0002*", b"pci:v00008086d*", b"platform:foo", b"of:Nbar*",
+            b"input:b0003*"]
+    a_mod = np.array([1, 4, 0, 3, 2, 5], dtype=np.uint32)   # module 5 has no hardware-bus alias
+    A, a_off = pack_strings(pats)
+    rowptr = np.array([0, 1, 2, 2, 3, 3, 4], dtype=np.uint32)
+    col = np.array([1, 2, 2, 4], dtype=np.uint32)
+    names = ["e1000", "r8169", "igb", "ahci", "tg3", "snd_x"]
+    safe = safe_module_names(names)
+    assert safe.tolist() == [1, 1, 1, 1, 1, 0]
+    devs = [b"pci:v00008086d00001234sv0sd0bc02sc00i00", b"usb:v1D6Bp0002d0001", b"acpi:PNP0C0A:"]
+    S, s_off = pack_strings(devs)
+    dev_off = np.array([0, 1, 1, 3, 3, 3], dtype=np.uint32)
+    extra_off = np.array([0, 1, 3, 3, 3, 5], dtype=np.uint32)
+    extra_ids = np.array([3, 0, 5, 4, 9], dtype=np.uint32)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    gpu_ctx.dep_graph_load(rowptr, col)
+    assert gpu_ctx.alias_hw_flags(6).tolist() == [1, 1, 1, 1, 1, 0]
+    off, ids = gpu_ctx.fleet_roots(S, s_off, dev_off, extra_off, extra_ids, safe)
+    # host 0: driver 1 (first match wins over the wider pattern of module 0), extra 3 -> 3 listed
+    # host 1: extras 0 and 5 -> 0 listed (5: unsafe name and no hardware alias; 4, 1, 2 held)
+    # host 2: driver 4; host 3: nothing; host 4: extra 4 listed (hardware alias, safe, nobody holds it)
+    assert off.tolist() == [0, 1, 2, 2, 2, 3]
+    assert ids.tolist() == [3, 0, 4]
+
+
+def test_fleet_medium_vs_oracle(gpu_ctx, oracle_mod):
+    """20000 hosts x ~20 devices against the 30000-pattern table; alias part of the
+    expectation by the CPU twin (itself pinned to glibc fnmatch in the CPU suite)"""
+    f = make_fleet(41, 30000, 20000, 20, 6)
+    off, ids = run_fleet(gpu_ctx, f)
+    w_off, w_ids = oracle_fleet(oracle_mod, gpu_ctx, f, use_twin=True)
+    assert np.array_equal(off, w_off)
+    assert np.array_equal(ids, w_ids)
+
+
+def test_fleet_full_size_tiled(gpu_ctx, oracle_mod):
+    """BASELINE-sized fleet (100000 hosts, ~100 devices each, 30000 patterns): the
+    fleet is 100 copies of 1000 distinct hosts, so the expected lists are the
+    oracle's lists of those 1000 hosts, repeated"""
+    base = make_fleet(51, 30000, 1000, 100, 8)
+    w_off, w_ids = oracle_fleet(oracle_mod, gpu_ctx, base, use_twin=True)
+    reps = 100
+    Hb, Nb, Xb = base["H"], base["N"], int(base["extra_off"][-1])
+    sb = int(base["s_off"][-1])
+    S = np.tile(base["S"][:sb], reps)
+    s_off = np.concatenate([[0], (base["s_off"][1:].astype(np.uint64)[None, :] +
+                                  (np.arange(reps, dtype=np.uint64) * sb)[:, None]).ravel()]).astype(np.uint32)
+    dev_off = np.concatenate([[0], (base["dev_off"][1:].astype(np.uint64)[None, :] +
+                                    (np.arange(reps, dtype=np.uint64) * Nb)[:, None]).ravel()]).astype(np.uint32)
+    extra_off = np.concatenate([[0], (base["extra_off"][1:].astype(np.uint64)[None, :] +
+                                      (np.arange(reps, dtype=np.uint64) * Xb)[:, None]).ravel()]).astype(np.uint32)
+    extra_ids = np.tile(base["extra_ids"], reps)
+    assert int(s_off[-1]) == sb * reps and len(dev_off) == Hb * reps + 1
+    gpu_ctx.alias_table_load(base["A"], base["a_off"], base["a_mod"])
+    gpu_ctx.dep_graph_load(base["rowptr"], base["col"])
+    off, ids = gpu_ctx.fleet_roots(S, s_off, dev_off, extra_off, extra_ids, base["safe"])
+    T = len(w_ids)
+    assert len(ids) == T * reps
+    assert np.array_equal(ids.reshape(reps, T), np.tile(w_ids, (reps, 1)))
+    want_off = np.concatenate([[0], (w_off[1:].astype(np.uint64)[None, :] +
+                                     (np.arange(reps, dtype=np.uint64) * T)[:, None]).ravel()]).astype(np.uint32)
+    assert np.array_equal(off, want_off)
