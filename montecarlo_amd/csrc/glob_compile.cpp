@@ -327,26 +327,103 @@ int mcx_parse_pattern(const uint8_t *pat_in, size_t n, bool normalize_dash, mcx_
     return 0;
 }
 
-void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, std::vector<uint32_t> &prog)
+namespace {
+/* the MCX_SET_WORDS words of one set entry */
+static void emit_set_entry(uint32_t pos, uint32_t id, const uint32_t *bits, std::vector<uint32_t> &prog)
+{
+    std::vector<uint8_t> in, notin;
+    for (unsigned b = 1; b < 256; ++b)
+        ((bits[b >> 5] >> (b & 31)) & 1u ? in : notin).push_back((uint8_t)b);
+    uint32_t w[MCX_SET_WORDS] = {pos | (id << 16), MCX_SET_GENERAL, 0u, 0u};
+    const std::vector<uint8_t> *list = nullptr;
+    if (in.size() <= MCX_SET_MEMBERS)
+        list = &in;
+    else if (notin.size() <= MCX_SET_MEMBERS)
+        list = &notin;
+    if (list) {
+        w[1] = (uint32_t)list->size() | (list == &notin ? 0x100u : 0u);
+        for (size_t i = 0; i < list->size(); ++i) {
+            if (i < 2)
+                w[1] |= (uint32_t)(*list)[i] << (16 + 8 * i);
+            else if (i < 6)
+                w[2] |= (uint32_t)(*list)[i] << (8 * (i - 2));
+            else
+                w[3] |= (uint32_t)(*list)[i] << (8 * (i - 6));
+        }
+    }
+    prog.insert(prog.end(), w, w + MCX_SET_WORDS);
+}
+} // namespace
+
+void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, const std::vector<uint32_t> &sets,
+                      std::vector<uint32_t> &prog, std::vector<uint32_t> *seg_words)
 {
     prog.push_back(MCX_HDR(ir.minlen, ir.flags, keylen, ir.segs.size()));
-    for (const auto &sg : ir.segs) {
-        uint32_t nchars = (uint32_t)sg.size(), nchunks = (nchars + 3u) / 4u;
+    for (size_t si = 0; si < ir.segs.size(); ++si) {
+        const auto &sg = ir.segs[si];
+        if (seg_words)
+            seg_words->push_back((uint32_t)prog.size());
+        const uint32_t nchars = (uint32_t)sg.size(), nchunks = (nchars + 3u) / 4u;
+        const uint32_t c0 = si == 0 ? keylen / 4u : 0u; /* chunks the index key covers */
         std::vector<uint32_t> setlist;
-        std::vector<uint32_t> chunks(2 * (size_t)nchunks, 0u);
+        std::vector<uint32_t> value(nchunks, 0u), mask(nchunks, 0u);
+        bool masked = false;
         for (uint32_t k = 0; k < nchars; ++k) {
             const Matcher &m = sg[k];
             uint32_t sh = (k & 3u) * 8u;
             if (m.kind == M_LIT) {
-                chunks[2 * (k / 4)] |= (uint32_t)m.byte << sh;
-                chunks[2 * (k / 4) + 1] |= 0xFFu << sh;
-            } else if (m.kind == M_SET) {
-                setlist.push_back(k | ((uint32_t)m.set << 16));
+                value[k / 4] |= (uint32_t)m.byte << sh;
+                mask[k / 4] |= 0xFFu << sh;
+            } else {
+                masked = true;
+                if (m.kind == M_SET)
+                    setlist.push_back(k | ((uint32_t)m.set << 16));
             }
         }
-        prog.push_back(nchars | ((uint32_t)setlist.size() << 16));
-        prog.insert(prog.end(), chunks.begin(), chunks.end());
-        prog.insert(prog.end(), setlist.begin(), setlist.end());
+        if (si > 0 && setlist.empty() && nchars >= 1 && nchars <= 3) {
+            /* header and chunk in one word; three bits say which bytes are literals */
+            uint32_t lit = 0;
+            for (uint32_t k = 0; k < nchars; ++k)
+                lit |= (sg[k].kind == M_LIT ? 1u : 0u) << k;
+            prog.push_back((value[0] & 0xFFFFFFu) | (nchars << 24) | (lit << 26) | MCX_SEG_INLINE);
+            continue;
+        }
+        prog.push_back(nchars | ((uint32_t)setlist.size() << 16) | (masked ? MCX_SEG_MASKED : 0u));
+        for (uint32_t c = c0; c < nchunks; ++c)
+            prog.push_back(value[c]);
+        if (masked) {
+            /* four bits per chunk: which of its bytes are literals */
+            std::vector<uint32_t> mw((nchunks - c0 + 7u) / 8u, 0u);
+            for (uint32_t c = c0; c < nchunks; ++c) {
+                uint32_t nib = 0;
+                for (uint32_t b = 0; b < 4; ++b)
+                    nib |= ((mask[c] >> (8u * b)) & 1u) << b;
+                mw[(c - c0) / 8u] |= nib << (4u * ((c - c0) % 8u));
+            }
+            prog.insert(prog.end(), mw.begin(), mw.end());
+        }
+        for (uint32_t e : setlist)
+            emit_set_entry(e & 0xFFFFu, e >> 16, &sets[(size_t)(e >> 16) * 8], prog);
+    }
+}
+
+void mcx_fill_slot(const mcx_pattern_ir &ir, uint32_t keylen, uint32_t orig, const std::vector<uint32_t> &sets,
+                   uint32_t *slot, std::vector<uint32_t> &ext)
+{
+    std::vector<uint32_t> one, seg_words;
+    mcx_emit_program(ir, keylen, sets, one, &seg_words);
+    std::fill(slot, slot + MCX_SLOT_WORDS, 0u);
+    slot[0] = one[0];
+    slot[1] = orig;
+    const size_t body = one.size() - 1;
+    if (ir.segs.size() <= MCX_DIR_SEGS && body <= MCX_SLOT_WORDS - MCX_SLOT_BODY) {
+        for (size_t k = 0; k < seg_words.size(); ++k) /* word of `one` -> word of the slot */
+            slot[MCX_SLOT_DIR + k / 4] |= (seg_words[k] - 1u + MCX_SLOT_BODY) << (8u * (k % 4));
+        std::copy(one.begin() + 1, one.end(), slot + MCX_SLOT_BODY);
+    } else {
+        slot[0] = MCX_HDR(ir.minlen, ir.flags | MCX_PF_EXT, keylen, ir.segs.size());
+        slot[MCX_SLOT_DIR] = (uint32_t)ext.size();
+        ext.insert(ext.end(), one.begin() + 1, one.end());
     }
 }
 
@@ -442,8 +519,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     });
     size_t n_idx = order.size();
     out.slot.assign(n_idx * (size_t)MCX_SLOT_WORDS, 0u);
-    out.sigorig.resize(2 * n_idx);
-    std::vector<uint32_t> one;
+    out.sig.resize(n_idx);
     struct Group {
         uint32_t start, count;
     };
@@ -456,27 +532,20 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
                 out.lens.push_back((uint32_t)keys[j].size());
         }
         groups.back().count++;
-        one.clear();
-        mcx_emit_program(irs[j], (uint32_t)keys[j].size(), one);
-        uint32_t *sl = &out.slot[k * (size_t)MCX_SLOT_WORDS];
-        if (one.size() <= MCX_SLOT_WORDS) {
-            std::copy(one.begin(), one.end(), sl);
-        } else {
-            sl[0] = MCX_HDR(irs[j].minlen, irs[j].flags | MCX_PF_EXT, keys[j].size(), irs[j].segs.size());
-            sl[1] = (uint32_t)out.ext.size();
-            out.ext.insert(out.ext.end(), one.begin(), one.end());
-        }
-        out.sigorig[2 * k] = sig_of(irs[j], keys[j].size());
-        out.sigorig[2 * k + 1] = j;
+        mcx_fill_slot(irs[j], (uint32_t)keys[j].size(), j, out.sets, &out.slot[k * (size_t)MCX_SLOT_WORDS],
+                      out.ext);
+        out.sig[k] = sig_of(irs[j], keys[j].size());
     }
-    /* the matchers read up to two words past a program: keep them in bounds */
+    /* the matchers read up to two words past a program, the screen up to three
+     * signatures past a group: keep them in bounds */
+    out.sig.insert(out.sig.end(), 4, 0u);
     out.slot.insert(out.slot.end(), 4, 0u);
     out.ext.insert(out.ext.end(), 4, 0u);
     /* hash table: at least twice as many slots as groups, never empty */
     size_t cap = 16;
-    while (cap < 2 * groups.size())
+    while (cap < 8 * groups.size())
         cap *= 2;
-    out.slots.assign(cap, mcx_slot_t{0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}});
+    out.slots.assign(cap, mcx_slot_t{0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}});
     for (const Group &g : groups) {
         const std::string &key = keys[order[g.start]];
         uint32_t a, b, kw[MCX_KEY_MAX / 4] = {0};
@@ -485,7 +554,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         size_t at = a & (cap - 1);
         while (out.slots[at].count != 0)
             at = (at + 1) & (cap - 1);
-        mcx_slot_t sl = mcx_slot_t{a, b, g.start, g.count, {0, 0, 0, 0, 0, 0, 0, 0}};
+        mcx_slot_t sl = mcx_slot_t{a, b, g.start, g.count, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}};
         memcpy(sl.key, kw, sizeof kw);
         out.slots[at] = sl;
     }

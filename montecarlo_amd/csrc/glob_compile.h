@@ -32,8 +32,7 @@ struct mcx_compiled_table {
     uint32_t P = 0;                  /* patterns in the source table          */
     std::vector<uint32_t> slot;      /* n_indexed x MCX_SLOT_WORDS, index order */
     std::vector<uint32_t> ext;       /* programs too long for a slot          */
-    std::vector<uint32_t> sigorig;   /* n_indexed x {gram signature, table
-                                        position}                             */
+    std::vector<uint32_t> sig;       /* n_indexed gram signatures, index order */
     std::vector<mcx_slot_t> slots;   /* open-addressing hash table, 2^k slots */
     std::vector<uint32_t> lens;      /* distinct key lengths, ascending       */
     std::vector<uint32_t> sets;      /* distinct bracket sets, 8 words each   */
@@ -47,9 +46,18 @@ struct mcx_compiled_table {
 int mcx_parse_pattern(const uint8_t *pat, size_t n, bool normalize_dash, mcx_compiled_table &sets_owner,
                       mcx_pattern_ir &out, std::string &err);
 
-/* Append the program of one parsed pattern to `prog`; keylen = leading
- * literals covered by the pattern's index key. */
-void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, std::vector<uint32_t> &prog);
+/* Append the program of one parsed pattern to `prog`: the header word, then
+ * the body.  keylen = leading literals covered by the pattern's index key
+ * (their whole chunks are left out of the body); sets = the table's 256-bit
+ * bracket sets, eight words each, by set number.  seg_words, if given, receives
+ * for every segment the word of `prog` its header was written to. */
+void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, const std::vector<uint32_t> &sets,
+                      std::vector<uint32_t> &prog, std::vector<uint32_t> *seg_words = nullptr);
+
+/* Fill the MCX_SLOT_WORDS words of one pattern's slot (orig = its position in
+ * the caller's table); a body the slot cannot hold is appended to ext. */
+void mcx_fill_slot(const mcx_pattern_ir &ir, uint32_t keylen, uint32_t orig, const std::vector<uint32_t> &sets,
+                   uint32_t *slot, std::vector<uint32_t> &ext);
 
 /* Whole table: parse, group by literal prefix, emit programs in group order
  * and build the hash index. */

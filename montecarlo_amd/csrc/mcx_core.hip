@@ -15,14 +15,16 @@ void mcx_free_table(mcx_ctx *ctx)
 {
     (void)hipFree(ctx->d_slot);
     (void)hipFree(ctx->d_ext);
-    (void)hipFree(ctx->d_sigorig);
+    (void)hipFree(ctx->d_sig);
+    (void)hipFree(ctx->d_lens);
     (void)hipFree(ctx->d_slots);
     (void)hipFree(ctx->d_sets);
     (void)hipFree(ctx->d_amod);
     (void)hipFree(ctx->d_hwtag);
     ctx->d_slot = nullptr;
     ctx->d_ext = nullptr;
-    ctx->d_sigorig = nullptr;
+    ctx->d_sig = nullptr;
+    ctx->d_lens = nullptr;
     ctx->d_slots = nullptr;
     ctx->d_sets = nullptr;
     ctx->d_amod = nullptr;

@@ -32,11 +32,11 @@ struct mcx_ctx {
     uint32_t n_indexed = 0;          /* patterns that can match anything       */
     uint32_t *d_slot = nullptr;      /* n_indexed program slots, index order   */
     uint32_t *d_ext = nullptr;       /* overflow programs                      */
-    uint32_t *d_sigorig = nullptr;   /* n_indexed x {gram signature, position} */
+    uint32_t *d_sig = nullptr;       /* n_indexed gram signatures (+ padding)  */
+    uint32_t *d_lens = nullptr;      /* nlens distinct key lengths             */
     mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
     uint32_t slot_mask = 0;
     uint32_t nlens = 0;
-    uint32_t lens[MCX_KEY_MAX + 1] = {0};
     uint32_t *d_sets = nullptr;
     uint32_t *d_amod = nullptr;
     uint8_t *d_hwtag = nullptr;

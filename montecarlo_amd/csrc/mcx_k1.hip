@@ -15,22 +15,29 @@
 /* ------------------------------------------------------------------------- */
 
 #define K1_THREADS 256
-#define K1_MAX_SPB 16                       /* strings per block, at most      */
+#define K1_WAVES (K1_THREADS / 64)
+#define K1_MAX_SPB 8                        /* strings per block, at most      */
 #define K1_OCC_WORDS 512                     /* 256 x 64-bit position sets      */
-#define K1_LDS_STR_BYTES 16384              /* staging buffer for a tile       */
-#define K1_MAX_HITS (K1_MAX_SPB * (MCX_KEY_MAX + 1))
+#define K1_LDS_STR_BYTES 8192               /* staging buffer for a tile       */
+#define K1_RING 2048u       /* survivors waiting for a program run, per block    */
+#define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
+#define K1_GROUP 16u        /* survivors one wave stages per pass                 */
+#define K1_SUB 8u           /* of which it runs eight at a time, eight lanes each */
+#define K1_STAGE_STRIDE (MCX_SLOT_WORDS + 1u) /* odd: lanes reading the same word
+                                                 of their own slot hit 32 banks  */
+#define K1_STAGE_WORDS (K1_GROUP * K1_STAGE_STRIDE + 4u)
 
-/* what the match kernel needs from the loaded table; passed by value, so the
- * key lengths sit in the kernel argument segment */
+/* what the match kernel needs from the loaded table; passed by value */
 struct k1_table_t {
     const uint32_t *slot;   /* n_indexed x MCX_SLOT_WORDS                       */
-    const uint32_t *ext;    /* overflow programs                               */
-    const uint2 *sigorig;   /* n_indexed x {gram signature, table position}    */
+    const uint32_t *ext;    /* overflow bodies                                 */
+    const uint32_t *sig;    /* n_indexed gram signatures                       */
     const mcx_slot_t *slots;
     const uint32_t *sets;
+    const uint32_t *lens;   /* nlens key lengths                               */
     uint32_t slot_mask;
     uint32_t nlens;
-    uint32_t lens[MCX_KEY_MAX + 1];
+    uint32_t nlens_magic;   /* ceil(2^32 / nlens): x / nlens = mulhi(x, magic) for x < 2^16 */
 };
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
@@ -68,6 +75,16 @@ struct GlobalProg {
     const uint32_t *p;
     __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
 };
+struct LdsProg {
+    lds_words_t w;
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return w[i]; }
+};
+/* the rare cases (a body in the overflow array, a string of more than 64 bytes)
+ * read their program through a generic pointer: LDS or global */
+struct FlatProg {
+    const uint32_t *p;
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
+};
 /* occurrence table of one string: entry b = 64-bit set of positions holding b */
 struct LdsOcc {
     lds_words_t w;
@@ -81,32 +98,34 @@ struct LdsBloom {
     __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return w[i]; }
 };
 
-#define K1_RING 1024u       /* survivors waiting for a program run, per block    */
-#define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
-#define K1_WAVES (K1_THREADS / 64)
-
-struct __attribute__((aligned(8))) k1_sig4_t {
-    uint2 v[4]; /* {signature, table position} of four consecutive patterns */
+struct __attribute__((aligned(4))) k1_sig4_t {
+    uint32_t v[4]; /* gram signatures of four consecutive patterns */
 };
 
 /*
  * One block (4 waves) = `spb` consecutive strings x the whole table.
- *  1. the tile's bytes are staged in LDS and every string gets its 256-bit
- *     gram set;
+ *  1. the tile's bytes are staged in LDS; every string gets its 256-bit gram
+ *     set and (up to 64 bytes) its occurrence table;
  *  2. one lane per (string, key length) hashes the string's prefix of that
  *     length and probes the prefix index; a hit names a group of patterns that
- *     all start with exactly those literal bytes;
- *  3. hits are cut into units of up to 256 consecutive patterns; the waves
- *     share the units, four patterns per lane, and keep the patterns whose
- *     gram signature is inside the string's gram set: survivors are compacted
- *     by ballot into one ring per block;
- *  4. survivors are run 64 at a time by as few waves as it takes (a wave with
- *     four live lanes costs as much as one with 64): every lane copies one
- *     survivor's program slot into LDS and runs it on its string; matches go
- *     to per-string min / count cells in LDS, stored at the end.
+ *     all start with exactly those literal bytes, and reserves the group's
+ *     units (up to 256 consecutive patterns each) in the block's unit space;
+ *  3. the waves share the units, four patterns per lane, and keep the patterns
+ *     whose gram signature is inside the string's gram set: survivors are
+ *     compacted by ballot into one ring per block.  The signatures of a wave's
+ *     next unit are requested before the current one is screened;
+ *  4. survivors are run eight per wave and pass, all waves at once (a pass
+ *     costs the same whatever its number of live lanes, so runs wait until
+ *     every wave has a full group, or for the end).  Eight lanes share one
+ *     survivor: they copy its slot into LDS, each lane computes the fit set of
+ *     one segment from the string's occurrence table, and the sets are put
+ *     together through lane shuffles.  Patterns in the overflow array and
+ *     strings of more than 64 bytes are run by one lane, position by position.
+ *     Matches go to per-string min / count cells in LDS, stored at the end.
  * The block owns its strings: no global atomics, no pre-initialised output.
  */
-__global__ void __launch_bounds__(K1_THREADS)
+template <bool BULK>
+__global__ void __launch_bounds__(K1_THREADS, 5)
 k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
                  uint32_t str_cap, uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
                  uint32_t *__restrict__ count
@@ -122,25 +141,34 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         if (threadIdx.x == 0)                                                \
             stamps[blockIdx.x * 16u + (i)] = __builtin_amdgcn_s_memtime();    \
     } while (0)
+    unsigned long long acc_stage = 0, acc_mask = 0, acc_comb = 0, acc_n = 0, tmark = 0;
+#define K1_TICK() (tmark = __builtin_amdgcn_s_memtime())
+#define K1_TOCK(acc) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tmark; tmark = now_; } while (0)
 #else
 #define K1_STAMP(i) do { } while (0)
+#define K1_TICK() do { } while (0)
+#define K1_TOCK(acc) do { } while (0)
 #endif
     K1_STAMP(0);
     /* dynamic LDS, sized by the launch for its strings-per-block:
-     * [spb occurrence tables][str_cap/4 + 5 words of string bytes][hit_start][hit_slot][hit_cnt][hit_upref + 1] */
+     * [spb occurrence tables][str_cap/4 + 5 words of string bytes]
+     * [hit_start][hit_slot][hit_cnt][hit_ub], max_hits words each */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
-    __shared__ uint32_t ring[K1_RING], ring_orig[K1_RING];
+    __shared__ uint32_t ring[K1_RING];
+    __shared__ uint32_t stage[BULK ? 1 : K1_WAVES][BULK ? 1 : K1_STAGE_WORDS];
+    constexpr uint32_t GROUP = BULK ? 64u : K1_GROUP; /* survivors one wave takes per pass */
     __shared__ uint32_t bloom[K1_MAX_SPB][MCX_BLOOM_WORDS];
     __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
     __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB];
-    __shared__ uint32_t nhits, ring_tail, ring_head;
+    __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
+    __shared__ uint32_t nhits, nunits_sh, ring_cum[2];
     const uint32_t max_hits = spb * T.nlens;
     uint32_t *occ_w = k1_lds;
     uint32_t *str_w = occ_w + spb * K1_OCC_WORDS;
     uint32_t *hit_start = str_w + str_cap / 4u + 5u;
     uint32_t *hit_slot = hit_start + max_hits;
     uint32_t *hit_cnt = hit_slot + max_hits;
-    uint32_t *hit_upref = hit_cnt + max_hits;
+    uint32_t *hit_ub = hit_cnt + max_hits;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -157,6 +185,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
      * string then sit in front of it in the buffer */
     const uint32_t shift = (use_lds && s_aligned) ? (gbase & 3u) : 0u;
 
+    if (tid < T.nlens)
+        key_lens[tid] = T.lens[tid];
     for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
         uint32_t so = s_off[t0 + i];
         str_at[i] = so - gbase + shift;
@@ -173,8 +203,9 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     if (tid == 0) {
         nhits = 0;
-        ring_tail = 0;
-        ring_head = 0;
+        nunits_sh = 0;
+        ring_cum[0] = 0;
+        ring_cum[1] = 0;
     }
     for (uint32_t w = tid; w < nstr * K1_OCC_WORDS; w += K1_THREADS)
         occ_w[w] = 0u;
@@ -213,10 +244,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         }
     }
 
+    K1_STAMP(3);
     /* ---- probe: last wave first, so that it overlaps the gram sets -------- */
+#ifdef MCX_K1_STAMPS
+    unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pt1 = pt0, pt2 = pt0;
+#endif
     const uint32_t nprobe = nstr * T.nlens;
     for (uint32_t pr = (K1_THREADS - 1u) - tid; pr < nprobe; pr += K1_THREADS) {
-        const uint32_t slot = pr / T.nlens, L = T.lens[pr - slot * T.nlens];
+        const uint32_t slot = __umulhi(pr, T.nlens_magic), L = key_lens[pr - slot * T.nlens];
         const uint32_t len = str_len[slot];
         if (L > len)
             continue;
@@ -239,6 +274,9 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 kw[k] &= 0xFFFFFFFFu >> (8u * (4u - (L & 3u)));
         uint32_t a, b;
         mcx_key_hash(kw, L, a, b);
+#ifdef MCX_K1_STAMPS
+        pt1 = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
             const mcx_slot_t sl = T.slots[at];
             if (sl.count == 0u)
@@ -248,7 +286,11 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
                 same = same && sl.key[k] == kw[k];
             if (same) {
-                uint32_t h = atomicAdd(&nhits, 1u);
+                /* the group's units take the next free places of the block's
+                 * unit space, in whatever order the hits arrive */
+                const uint32_t units = (sl.count + K1_UNIT - 1u) / K1_UNIT;
+                const uint32_t h = atomicAdd(&nhits, 1u);
+                hit_ub[h] = atomicAdd(&nunits_sh, units);
                 hit_start[h] = sl.start;
                 hit_slot[h] = slot;
                 hit_cnt[h] = sl.count;
@@ -256,108 +298,228 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             }
         }
     }
+#ifdef MCX_K1_STAMPS
+    pt2 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == K1_THREADS - 1u) {
+        stamps[blockIdx.x * 16u + 14u] = pt1 - pt0;
+        stamps[blockIdx.x * 16u + 15u] = pt2 - pt1;
+    }
+#endif
     __syncthreads();
     K1_STAMP(2);
 
-    /* ---- exclusive prefix sum of the hits' unit counts (first wave) ------- */
-    const uint32_t nh = nhits;
-    if (wave == 0) {
-        const uint32_t per = (nh + 63u) / 64u;
-        const uint32_t lo = lane * per, hi = min(lo + per, nh);
-        uint32_t sum = 0;
-        for (uint32_t h = lo; h < hi; ++h)
-            sum += (hit_cnt[h] + K1_UNIT - 1u) / K1_UNIT;
-        uint32_t incl = sum;
-#pragma unroll
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d)
-                incl += o;
-        }
-        uint32_t run = incl - sum;
-        if (lane == 0)
-            hit_upref[0] = 0;
-        for (uint32_t h = lo; h < hi; ++h) {
-            run += (hit_cnt[h] + K1_UNIT - 1u) / K1_UNIT;
-            hit_upref[h + 1] = run;
-        }
-    }
-    __syncthreads();
-
     /* ---- units -> survivors ----------------------------------------------- */
-    K1_STAMP(3);
-    const uint32_t nunits = hit_upref[nh];
+    const uint32_t nh = nhits;
+    const uint32_t nunits = nunits_sh;
+    /* the first 64 hits live in registers, one per lane */
+    uint32_t my_ub = 0, my_units = 0, my_start = 0, my_cnt = 0, my_slot = 0;
+    if (lane < nh) {
+        my_ub = hit_ub[lane];
+        my_cnt = hit_cnt[lane];
+        my_units = (my_cnt + K1_UNIT - 1u) / K1_UNIT;
+        my_start = hit_start[lane];
+        my_slot = hit_slot[lane];
+    }
+    /* unit u -> first pattern, number of patterns, string slot */
+    auto unit_at = [&](uint32_t u, uint32_t &k0, uint32_t &n, uint32_t &slot) __attribute__((always_inline)) {
+        const unsigned long long m = __ballot(u - my_ub < my_units); /* lanes without a hit: 0 units */
+        uint32_t ub, cnt, start;
+        if (m) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(m);
+            ub = __shfl(my_ub, src, 64);
+            cnt = __shfl(my_cnt, src, 64);
+            start = __shfl(my_start, src, 64);
+            slot = __shfl(my_slot, src, 64);
+        } else {
+            /* more than 64 hits in the block: the rest is searched in LDS */
+            uint32_t h = 64u;
+            while (u - hit_ub[h] >= (hit_cnt[h] + K1_UNIT - 1u) / K1_UNIT)
+                ++h;
+            ub = hit_ub[h];
+            cnt = hit_cnt[h];
+            start = hit_start[h];
+            slot = hit_slot[h];
+        }
+        const uint32_t j = u - ub;
+        k0 = start + K1_UNIT * j;
+        n = min(K1_UNIT, cnt - K1_UNIT * j);
+    };
+    auto load_sigs = [&](uint32_t k0, uint32_t n, k1_sig4_t &out) __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t jj = 0; jj < 4; ++jj)
+            out.v[jj] = 0u;
+        /* a partly used group of four reads up to three signatures past the
+         * unit: the array is padded for that */
+        if (4u * lane < n)
+            out = *(const k1_sig4_t *)(T.sig + k0 + 4u * lane);
+    };
 
-    /* run the n survivors ring[from .. from+n), one per lane of this wave */
-    auto run_survivors = [&](uint32_t from, uint32_t n) {
-        const bool have = lane < n;
-        const uint32_t e = have ? ring[(from + lane) & (K1_RING - 1u)] : 0u;
-        const uint32_t orig = have ? ring_orig[(from + lane) & (K1_RING - 1u)] : 0u;
-        const uint32_t k = e & 0x03FFFFFFu, slot = e >> 26;
-        K1_STAMP(7);
-        if (have) {
-            /* the program is read in place: its slot is one 128-byte line */
+    /* run n <= K1_GROUP survivors ring[from .. from+n): all their slots are
+     * copied to LDS in one go (64 lanes x 2 x 16 bytes = 16 slots), then
+     * lanes 8g .. 8g+7 share survivor 8t+g in sub-pass t */
+    /* one lane, position by position: bodies in the overflow array, strings of
+     * more than 64 bytes, tiles read in place */
+    auto slow_match = [&](const uint32_t *prog, uint32_t at, uint32_t hdr, uint32_t slot, uint32_t len)
+        __attribute__((always_inline)) {
+        const FlatProg fp{prog};
+        if (use_lds)
+            return mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets);
+        return mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len}, len, T.sets);
+    };
+    uint32_t *my_stage = stage[BULK ? 0u : wave];
+    /* many strings per block: a lane per survivor, its slot read in place; the
+     * waves of the other blocks on the CU cover the memory latency */
+    auto run_lanes = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
+        if (lane < n) {
+            const uint32_t e = ring[(from + lane) & (K1_RING - 1u)];
+            const uint32_t slot = e >> 26;
             const uint32_t len = str_len[slot];
-            const GlobalProg lp{T.slot + (size_t)k * MCX_SLOT_WORDS};
-            const uint32_t hdr = lp[0];
+            const uint32_t *sp = T.slot + (size_t)(e & 0x03FFFFFFu) * MCX_SLOT_WORDS;
+            const uint32_t hdr = sp[0];
             const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
-            const GlobalProg gp{is_ext ? T.ext : lp.p};
-            const uint32_t at = is_ext ? lp[1] : 0u;
             bool ok;
-            if (use_lds && len <= MCX_OCC_MAX_LEN) {
-                /* the probe compared the key's bytes: skip them */
-                LdsOcc occ{(lds_words_t)occ_w + slot * K1_OCC_WORDS};
-                LdsStr str{(lds_words_t)str_w, str_at[slot]};
-                ok = mcx_prog_match_occ(gp, at, str, occ, len, MCX_HDR_KEYLEN(hdr), T.sets);
-            } else if (use_lds) {
-                LdsStr str{(lds_words_t)str_w, str_at[slot]};
-                ok = mcx_prog_match(gp, at, str, len, T.sets);
+            if (is_ext || !use_lds || len > MCX_OCC_MAX_LEN) {
+                ok = slow_match(is_ext ? T.ext : sp, is_ext ? sp[MCX_SLOT_DIR] : MCX_SLOT_BODY, hdr, slot, len);
             } else {
-                GlobalStr str{S + gbase + str_at[slot], len};
-                ok = mcx_prog_match(gp, at, str, len, T.sets);
+                LdsOcc occ{(lds_words_t)occ_w + slot * K1_OCC_WORDS};
+                ok = mcx_slot_match_occ(GlobalProg{sp}, occ, len, T.sets);
             }
-            K1_STAMP(8);
             if (ok) {
-                atomicMin(&res_first[slot], orig);
+                atomicMin(&res_first[slot], sp[1]);
                 atomicAdd(&res_count[slot], 1u);
             }
         }
+    };
+    auto run_groups = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
+        K1_TICK();
+#pragma unroll
+        for (uint32_t t = 0; t < K1_GROUP * (MCX_SLOT_WORDS / 4u) / 64u; ++t) {
+            const uint32_t piece = lane + 64u * t, i = piece / (MCX_SLOT_WORDS / 4u),
+                           quarter = piece % (MCX_SLOT_WORDS / 4u);
+            if (i < n) {
+                const uint32_t kk = ring[(from + i) & (K1_RING - 1u)] & 0x03FFFFFFu;
+                const uint4 v = *(const uint4 *)(T.slot + (size_t)kk * MCX_SLOT_WORDS + 4u * quarter);
+                uint32_t *dst = my_stage + i * K1_STAGE_STRIDE + 4u * quarter;
+                dst[0] = v.x;
+                dst[1] = v.y;
+                dst[2] = v.z;
+                dst[3] = v.w;
+            }
+        }
+        K1_STAMP(7);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        K1_TOCK(acc_stage);
+        const uint32_t k = lane & 7u;
+        for (uint32_t g = lane >> 3; g < n; g += K1_SUB) {
+            K1_TICK();
+            /* the eight lanes of a group stay together: g < n is the same for them */
+            const uint32_t slot = ring[(from + g) & (K1_RING - 1u)] >> 26;
+            const uint32_t *st = my_stage + g * K1_STAGE_STRIDE;
+            const LdsProg lp{(lds_words_t)st};
+            const uint32_t hdr = lp[0];
+            const uint32_t len = str_len[slot];
+            const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
+            bool ok = false;
+            if (is_ext || !use_lds || len > MCX_OCC_MAX_LEN) {
+                /* rare: one lane, position by position */
+                if (k == 0u) {
+                    ok = slow_match(is_ext ? T.ext : st, is_ext ? lp[MCX_SLOT_DIR] : MCX_SLOT_BODY, hdr, slot, len);
+                }
+            } else {
+                /* lane k of the group prepares the steps of segments k and
+                 * k + 8; the state of the chain then moves one lane to the right
+                 * per step (row_shr:1 stays inside the group except for lane 0,
+                 * which feeds the start state), so after eight steps lane 7
+                 * holds the state behind segment 7, and after eight more, fed
+                 * with that, the state behind segment 15 */
+                const uint32_t nseg = MCX_HDR_NSEG(hdr);
+                const uint64_t all = len >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << len) - 1u);
+                mcx_step_t s0 = mcx_step_none(), s1 = mcx_step_none();
+                const bool pre = mcx_precheck(hdr, len);
+                if (pre) {
+                    LdsOcc occ{(lds_words_t)occ_w + slot * K1_OCC_WORDS};
+                    if (k < nseg) {
+                        const mcx_seg_t sg = mcx_seg_at(lp, mcx_dir_word(lp, k), k, hdr);
+                        s0 = mcx_step_make(hdr, len, k, mcx_seg_mask(lp, sg, occ, all, T.sets), sg.nchars);
+                    }
+                    if (k + 8u < nseg) {
+                        const mcx_seg_t sg = mcx_seg_at(lp, mcx_dir_word(lp, k + 8u), k + 8u, hdr);
+                        s1 = mcx_step_make(hdr, len, k + 8u, mcx_seg_mask(lp, sg, occ, all, T.sets), sg.nchars);
+                    }
+                }
+                K1_TOCK(acc_mask);
+                uint32_t state = MCX_STATE_START;
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)state, 0x111, 0xF, 0xF, false);
+                    state = mcx_step_apply(s0, len, k == 0u ? MCX_STATE_START : left);
+                }
+                if (__any(nseg > 8u)) {
+                    const uint32_t carry = __shfl(state, (int)((lane & ~7u) + 7u), 64);
+                    state = carry;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j) {
+                        const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)state, 0x111, 0xF, 0xF, false);
+                        state = mcx_step_apply(s1, len, k == 0u ? carry : left);
+                    }
+                }
+                ok = pre && k == 7u && MCX_STATE_OK(state) != 0u;
+            }
+            if (ok) {
+                atomicMin(&res_first[slot], lp[1]);
+                atomicAdd(&res_count[slot], 1u);
+            }
+            K1_TOCK(acc_comb);
+#ifdef MCX_K1_STAMPS
+            ++acc_n;
+#endif
+        }
+        K1_STAMP(8);
         K1_STAMP(9);
+        /* the staging area is reused by this wave's next pass */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    auto run_survivors = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
+        if constexpr (BULK)
+            run_lanes(from, n);
+        else
+            run_groups(from, n);
+    };
 
-    /* the block walks the units in rounds of K1_WAVES (one unit per wave);
-     * after every round the survivors beyond a multiple of 64 stay in the
-     * ring, the others are run */
+    /* the block walks the units in rounds of K1_WAVES (one unit per wave) */
     const uint32_t nrounds = (nunits + K1_WAVES - 1u) / K1_WAVES;
-    uint32_t h = 0;
+    /* Ring bookkeeping without a second barrier per round: survivors of round r
+     * are counted in ring_cum[r & 1], which only grows.  After the round's
+     * barrier that cell is stable until round r+2 (which cannot start before
+     * every wave has passed the barrier of round r+1), so every thread reads
+     * the same value and keeps the ring's head and tail in registers. */
+    uint32_t head = 0, tail = 0, seen0 = 0, seen1 = 0;
+    uint32_t k0 = 0, n = 0, slot = 0;
+    k1_sig4_t cur;
+    if (wave < nunits) {
+        unit_at(wave, k0, n, slot);
+        load_sigs(k0, n, cur);
+    }
     for (uint32_t r = 0; r < nrounds; ++r) {
         const uint32_t u = r * K1_WAVES + wave;
+        /* request the next unit's signatures before this one's are looked at */
+        uint32_t nk0 = 0, nn = 0, nslot = 0;
+        k1_sig4_t nxt;
+        const bool more = u + K1_WAVES < nunits;
+        if (more) {
+            unit_at(u + K1_WAVES, nk0, nn, nslot);
+            load_sigs(nk0, nn, nxt);
+        }
         if (u < nunits) {
-            while (hit_upref[h + 1] <= u)
-                ++h;
-            const uint32_t j = u - hit_upref[h];
-            const uint32_t k0 = hit_start[h] + K1_UNIT * j;
-            const uint32_t n = min(K1_UNIT, hit_cnt[h] - K1_UNIT * j);
-            const uint32_t slot = hit_slot[h];
-            k1_sig4_t cur;
-#pragma unroll
-            for (uint32_t jj = 0; jj < 4; ++jj)
-                cur.v[jj] = make_uint2(0u, 0u);
-            if (4u * lane + 4u <= n) {
-                cur = *(const k1_sig4_t *)(T.sigorig + k0 + 4u * lane);
-            } else {
-#pragma unroll
-                for (uint32_t jj = 0; jj < 4; ++jj)
-                    if (4u * lane + jj < n)
-                        cur.v[jj] = T.sigorig[k0 + 4u * lane + jj];
-            }
             LdsBloom bl{(lds_words_t)bloom[slot]};
             bool pass[4];
             uint32_t npass = 0;
 #pragma unroll
             for (uint32_t jj = 0; jj < 4; ++jj) {
-                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj].x, bl);
+                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj], bl);
                 npass += pass[jj] ? 1u : 0u;
             }
             /* wave-wide exclusive scan of npass, one reservation per wave */
@@ -372,37 +534,50 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             if (wtotal) {
                 uint32_t base = 0;
                 if (lane == 0)
-                    base = atomicAdd(&ring_tail, wtotal);
-                base = __shfl(base, 0, 64);
+                    base = atomicAdd(&ring_cum[r & 1u], wtotal);
+                base = tail + (__shfl(base, 0, 64) - ((r & 1u) ? seen1 : seen0));
                 uint32_t at = base + incl - npass;
 #pragma unroll
                 for (uint32_t jj = 0; jj < 4; ++jj)
                     if (pass[jj]) {
                         ring[at & (K1_RING - 1u)] = (slot << 26) | (k0 + 4u * lane + jj);
-                        ring_orig[at & (K1_RING - 1u)] = cur.v[jj].y;
                         ++at;
                     }
             }
         }
+        if (more) {
+            k0 = nk0;
+            n = nn;
+            slot = nslot;
+            cur = nxt;
+        }
         __syncthreads();
         {
-            /* full groups of 64 go now; at most K1_WAVES x 256 new survivors a
-             * round plus 63 left over fit the ring */
-            const uint32_t head = ring_head, avail = ring_tail - head;
-            const uint32_t groups = avail / 64u;
+            /* whole rounds of K1_WAVES full groups go now; fewer than that many
+             * survivors wait for more.  At most K1_WAVES x K1_UNIT new survivors
+             * a round plus what was left over fit the ring. */
+            const uint32_t now = ring_cum[r & 1u];
+            tail += now - ((r & 1u) ? seen1 : seen0);
+            if (r & 1u)
+                seen1 = now;
+            else
+                seen0 = now;
+            const uint32_t avail = tail - head;
+            const uint32_t groups = (avail / GROUP) & ~(K1_WAVES - 1u);
             for (uint32_t g = wave; g < groups; g += K1_WAVES)
-                run_survivors(head + 64u * g, 64u);
-            __syncthreads();
-            if (tid == 0)
-                ring_head = head + 64u * groups;
-            __syncthreads();
+                run_survivors(head + GROUP * g, GROUP);
+            head += GROUP * groups;
+            /* next round's survivors may only overwrite entries that have been
+             * run: make sure of it when this round ran a large part of the ring */
+            if (GROUP * groups > K1_RING / 4u)
+                __syncthreads();
         }
     }
     K1_STAMP(4);
     {
-        /* fewer than 64 are left: split them over the waves, a wave's time
-         * follows its slowest lane, not its lane count */
-        const uint32_t head = ring_head, avail = ring_tail - head;
+        /* fewer than K1_WAVES groups are left: split them over the waves, a
+         * wave's time follows its slowest lane, not its lane count */
+        const uint32_t avail = tail - head;
         const uint32_t share = (avail + K1_WAVES - 1u) / K1_WAVES;
         const uint32_t from = wave * share;
         if (from < avail)
@@ -415,6 +590,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         count[t0 + i] = res_count[i];
     }
     K1_STAMP(6);
+#ifdef MCX_K1_STAMPS
+    if (threadIdx.x == 0) {
+        stamps[blockIdx.x * 16u + 10u] = acc_stage;
+        stamps[blockIdx.x * 16u + 11u] = acc_mask;
+        stamps[blockIdx.x * 16u + 12u] = acc_comb;
+        stamps[blockIdx.x * 16u + 13u] = acc_n;
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(256)
@@ -467,7 +650,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     mcx_free_table(ctx);
     if ((rc = mcx_dev_upload(ctx, &ctx->d_slot, t.slot.data(), t.slot.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_ext, t.ext.data(), t.ext.size())) != 0 ||
-        (rc = mcx_dev_upload(ctx, &ctx->d_sigorig, t.sigorig.data(), t.sigorig.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_sig, t.sig.data(), t.sig.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_lens, t.lens.data(), t.lens.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_slots, t.slots.data(), t.slots.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_sets, t.sets.data(), t.sets.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_amod, a_mod, (size_t)P)) != 0 ||
@@ -477,13 +661,11 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->P = P;
-    ctx->n_indexed = (uint32_t)(t.sigorig.size() / 2);
+    ctx->n_indexed = (uint32_t)t.sig.size() - 4u; /* the array ends in four words of padding */
     ctx->slot_mask = (uint32_t)t.slots.size() - 1u;
     ctx->nlens = (uint32_t)t.lens.size();
-    for (uint32_t k = 0; k < ctx->nlens; ++k)
-        ctx->lens[k] = t.lens[k];
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
-    ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sigorig.size() + t.sets.size()) +
+    ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.sets.size() + t.lens.size()) +
                        sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + 4 * (uint64_t)P + t.hw_tag.size();
     ctx->table_loaded = true;
     return MCX_OK;
@@ -521,22 +703,27 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     if (N == 0)
         return MCX_OK;
     /* few strings: one per block, so that the whole chip has work;
-     * many strings: up to 64 per block */
+     * many strings: up to K1_MAX_SPB per block */
     uint32_t spb = (N + 2047u) / 2048u;
     if (spb > K1_MAX_SPB)
         spb = K1_MAX_SPB;
+    if (const char *e = getenv("MCX_K1_SPB_TRY")) { /* TEMP experiment */
+        uint32_t v = (uint32_t)atoi(e);
+        if (v >= 1 && v <= K1_MAX_SPB)
+            spb = v;
+    }
     uint32_t blocks = (N + spb - 1u) / spb;
     k1_table_t T;
     T.slot = ctx->d_slot;
     T.ext = ctx->d_ext;
-    T.sigorig = (const uint2 *)ctx->d_sigorig;
+    T.sig = ctx->d_sig;
+    T.lens = ctx->d_lens;
     T.slots = ctx->d_slots;
     T.sets = ctx->d_sets;
     T.slot_mask = ctx->slot_mask;
     T.nlens = ctx->nlens;
-    for (uint32_t k = 0; k <= MCX_KEY_MAX; ++k)
-        T.lens[k] = k < ctx->nlens ? ctx->lens[k] : 0u;
-    /* staging buffer: 256 bytes per string of the tile, between 1 KiB and 16 KiB;
+    T.nlens_magic = ctx->nlens ? (uint32_t)((((uint64_t)1 << 32) + ctx->nlens - 1u) / ctx->nlens) : 0u;
+    /* staging buffer: 256 bytes per string of the tile, between 1 KiB and 8 KiB;
      * a tile that needs more is read in place */
     uint32_t str_cap = spb * 256u;
     if (str_cap < 1024u)
@@ -549,11 +736,20 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     if (!g_k1_stamps)
         (void)hipMalloc((void **)&g_k1_stamps, 16u * 8u * 65536u);
     g_k1_stamp_blocks = blocks < 65536u ? blocks : 65536u;
-    k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
-                                                               d_first, d_count, g_k1_stamps);
+    k1_match_indexed<false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
+                                                                      d_first, d_count, g_k1_stamps);
 #else
-    k1_match_indexed<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
-                                                               d_first, d_count);
+    /* a block with one or two strings is latency bound: eight lanes per
+     * survivor; more strings give the waves full groups: a lane per survivor */
+    bool bulk = spb > 2u;
+    if (const char *e = getenv("MCX_K1_BULK_TRY")) /* TEMP experiment */
+        bulk = atoi(e) != 0;
+    if (bulk)
+        k1_match_indexed<true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned,
+                                                                         T, d_first, d_count);
+    else
+        k1_match_indexed<false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned,
+                                                                          T, d_first, d_count);
 #endif
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;

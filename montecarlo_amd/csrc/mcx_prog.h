@@ -11,20 +11,37 @@
  * (posix/fnmatch_loop.c, the '*' case), without its recursion.
  *
  * Encoding, 32-bit words:
- *   word 0        minlen | flags | keylen | nseg (MCX_HDR)
- *   per segment   header: nchars (0..15) | nsets (16..31)
- *                 ceil(nchars/4) chunks of two words {value, mask}: string
- *                 bytes q+4c .. q+4c+3, read as one little-endian word w,
- *                 fit iff ((w ^ value) & mask) == 0.  A literal has mask byte
- *                 0xFF, '?' and set positions and the padding of the last
- *                 chunk have mask byte 0.
- *                 nsets words {position in segment (0..15) | set number
- *                 (16..31)}: the byte there must be in that 256-bit set.
+ *   header        minlen | flags | keylen | nseg (MCX_HDR)
+ *   body, per segment:
+ *     segment header: nchars (bits 0..15) | nsets (16..29) | masked (31)
+ *     chunks: the segment's matchers four at a time.  String bytes q+4c ..
+ *       q+4c+3 are read as one little-endian word w; chunk c fits iff
+ *       ((w ^ value) & mask) == 0.  A literal has mask byte 0xFF; '?', set
+ *       positions and the padding of the last chunk have mask byte 0.  One
+ *       value word per chunk; a segment of literals only needs no masks (they
+ *       follow from nchars), a "masked" segment appends four mask bits per
+ *       chunk (bit b: byte b is a literal), eight chunks to a word.
+ *       The first segment omits its first keylen/4 chunks: a string reaches a
+ *       pattern through the prefix index, which has compared those bytes.
+ *     nsets entries of MCX_SET_WORDS words, one per bracket set in the segment:
+ *       {position in segment (bits 0..15) | set number (16..31)},
+ *       {n (0..7) | negated (8) | member 0 | member 1}, {members 2..5},
+ *       {members 6..9}: the byte at that position must be one of the n member
+ *       bytes (negated: none of them, and not NUL).  A set with more than ten
+ *       members either way has n = MCX_SET_GENERAL and is looked up in the
+ *       table's 256-bit sets by its number.
+ *     A later segment of one to three literals or '?' (the "sv", "bc", "ic" of
+ *     a modalias) is a single word, header and chunk at once: the bytes (bits
+ *     0..23) | nchars (24..25) | which bytes are literals (26..28) | inline (30).
  *
- * Storage: every indexed pattern owns one fixed slot of MCX_SLOT_WORDS words.
- * A program that fits lives in its slot; a longer one lives in an overflow
- * array and its slot holds only {header with MCX_PF_EXT set, word offset into
- * the overflow array}.
+ * Storage: every indexed pattern owns one slot of MCX_SLOT_WORDS words:
+ *   {header, position of the pattern in the caller's table, four words of
+ *    segment directory, body ...}
+ * The directory holds, one byte each, the slot word at which the header of
+ * segment 0..15 sits, so that the segments of one pattern can be evaluated by
+ * different lanes.  A pattern with more than sixteen segments or a body that
+ * does not fit lives in an overflow array, its slot being
+ *   {header with MCX_PF_EXT, table position, word offset of the body there}.
  *
  * Gram signature: a string that matches a pattern contains every run of
  * literals of the pattern, hence every 4-byte window ("gram") of such a run.
@@ -60,6 +77,14 @@
 #define MCX_PF_EXT        8u   /* slot holds {header, overflow offset} only */
 
 #define MCX_SLOT_WORDS    32u
+#define MCX_SLOT_DIR      2u   /* segment directory word of a slot */
+#define MCX_SLOT_BODY     6u   /* first body word of a slot */
+#define MCX_DIR_SEGS      16u  /* segments the directory can name */
+#define MCX_SEG_MASKED     0x80000000u
+#define MCX_SEG_INLINE     0x40000000u
+#define MCX_SET_WORDS      4u
+#define MCX_SET_MEMBERS    10u
+#define MCX_SET_GENERAL    0xFFu
 #define MCX_BLOOM_WORDS   8u
 #define MCX_BLOOM_FREE    255u /* the bit every string has */
 
@@ -85,6 +110,7 @@ typedef struct {
     uint32_t start; /* first pattern of the group, in index order */
     uint32_t count;
     uint32_t key[8]; /* the literal prefix itself, zero padded */
+    uint32_t pad[4]; /* 64 bytes: a slot never straddles a cache line */
 } mcx_slot_t;
 
 /* Hash of a key of `len` <= MCX_KEY_MAX bytes held in little-endian words
@@ -137,36 +163,114 @@ MCX_UNROLL
  *                              (they are always masked), but reads up to 8
  *                              bytes past the end are safe
  *   uint32_t byte(uint32_t q)  byte q, q < length
- * Prog is any type whose operator[](w) returns word w of the program.
+ * Prog is any type whose operator[](w) returns word w of the program body;
+ * reads of up to two words past the body are safe (their values are masked).
  */
-template <class Prog, class Str>
-MCX_HD bool mcx_seg_rest(const Prog &p, uint32_t chunks, uint32_t first_chunk, uint32_t nchunks,
-                         uint32_t setlist, uint32_t nsets, const Str &s, uint32_t q, const uint32_t *sets)
+
+/* four mask bits -> four mask bytes */
+MCX_HD uint32_t mcx_expand_mask(uint32_t nib)
 {
-    for (uint32_t c = first_chunk; c < nchunks; ++c)
-        if ((s.word(q + 4u * c) ^ p[chunks + 2u * c]) & p[chunks + 2u * c + 1u])
+    return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+}
+
+/* layout of segment k whose header sits at word w */
+struct mcx_seg_t {
+    uint32_t nchars, nsets, nchunks, c0; /* c0: chunks the index key covers      */
+    uint32_t values;                     /* word of chunk 0's value (if stored)  */
+    uint32_t masks;                      /* first mask word of a masked segment  */
+    uint32_t kind;                       /* 0 literals only, 1 masked, 2 inline  */
+    uint32_t inline_mask;
+    uint32_t setlist, next;
+};
+
+template <class Prog>
+MCX_HD mcx_seg_t mcx_seg_at(const Prog &p, uint32_t w, uint32_t k, uint32_t hdr)
+{
+    mcx_seg_t g;
+    const uint32_t sh = p[w];
+    const bool inl = (sh & MCX_SEG_INLINE) != 0u;
+    g.nchars = inl ? ((sh >> 24) & 3u) : (sh & 0xFFFFu);
+    g.nsets = inl ? 0u : ((sh >> 16) & 0x3FFFu);
+    g.kind = inl ? 2u : (sh >> 31);
+    g.inline_mask = mcx_expand_mask(sh >> 26) & 0x00FFFFFFu;
+    g.nchunks = (g.nchars + 3u) >> 2;
+    g.c0 = k == 0u ? (MCX_HDR_KEYLEN(hdr) >> 2) : 0u;
+    const uint32_t stored = g.nchunks - g.c0;
+    /* an inline segment is its own value word: its mask hides the header bits */
+    g.values = inl ? w : w + 1u - g.c0;
+    g.masks = w + 1u + stored;
+    g.setlist = inl ? w + 1u : g.masks + (g.kind == 1u ? (stored + 7u) / 8u : 0u);
+    g.next = g.setlist + MCX_SET_WORDS * g.nsets;
+    return g;
+}
+
+/* value and mask of chunk c (c0 <= c; a chunk past the last one, read ahead and
+ * never used, gets whatever lies there) */
+template <class Prog>
+MCX_HD void mcx_chunk(const Prog &p, const mcx_seg_t &g, uint32_t c, uint32_t &v, uint32_t &m)
+{
+    v = p[g.values + c];
+    const uint32_t r = c - g.c0;
+    const uint32_t mw = p[g.masks + (r >> 3)];
+    const uint32_t left = g.nchars > 4u * c ? g.nchars - 4u * c : 0u;
+    const uint32_t implied = left >= 4u ? 0xFFFFFFFFu : (left ? 0xFFFFFFFFu >> (8u * (4u - left)) : 0u);
+    const uint32_t stored = mcx_expand_mask(mw >> (4u * (r & 7u)));
+    m = g.kind == 0u ? implied : (g.kind == 1u ? stored : g.inline_mask);
+}
+
+/* member i < MCX_SET_MEMBERS of a set entry whose words 1..3 are w1, w2, w3 */
+MCX_HD uint32_t mcx_set_member(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i)
+{
+    const uint32_t w = i < 2u ? (w1 >> 16) : (i < 6u ? w2 : w3);
+    const uint32_t sh = i < 2u ? 8u * i : (i < 6u ? 8u * (i - 2u) : 8u * (i - 6u));
+    return (w >> sh) & 0xFFu;
+}
+
+/* is byte ch accepted by the set entry at word e of p ? */
+template <class Prog>
+MCX_HD bool mcx_set_has(const Prog &p, uint32_t e, uint32_t ch, const uint32_t *sets)
+{
+    const uint32_t w0 = p[e], w1 = p[e + 1u], w2 = p[e + 2u], w3 = p[e + 3u];
+    const uint32_t n = w1 & 0xFFu;
+    if (n == MCX_SET_GENERAL)
+        return ((sets[(w0 >> 16) * 8u + (ch >> 5)] >> (ch & 31u)) & 1u) != 0u;
+    bool in = false;
+    for (uint32_t i = 0; i < n; ++i)
+        in = in || mcx_set_member(w1, w2, w3, i) == ch;
+    return ((w1 >> 8) & 1u) ? (!in && ch != 0u) : in;
+}
+
+template <class Prog, class Str>
+MCX_HD bool mcx_seg_rest(const Prog &p, const mcx_seg_t &g, uint32_t first_chunk, const Str &s, uint32_t q,
+                         const uint32_t *sets)
+{
+    for (uint32_t c = first_chunk; c < g.nchunks; ++c) {
+        uint32_t v, m;
+        mcx_chunk(p, g, c, v, m);
+        if ((s.word(q + 4u * c) ^ v) & m)
             return false;
-    for (uint32_t k = 0; k < nsets; ++k) {
-        uint32_t e = p[setlist + k];
-        uint32_t ch = s.byte(q + (e & 0xFFFFu));
-        if (!((sets[(e >> 16) * 8u + (ch >> 5)] >> (ch & 31u)) & 1u))
+    }
+    for (uint32_t k = 0; k < g.nsets; ++k) {
+        const uint32_t e = g.setlist + MCX_SET_WORDS * k;
+        if (!mcx_set_has(p, e, s.byte(q + (p[e] & 0xFFFFu)), sets))
             return false;
     }
     return true;
 }
 
 /*
- * Does the compiled pattern p (header at word `at`) match s[0..len) ?
- * Every segment is placed the same way: leftmost fit inside a window [lo, hi]
- * of start positions (a single position for the two anchored kinds), so that
- * lanes working on different patterns stay in one instruction stream.  When
- * the segment starts with a literal, the four start positions covered by one
- * string word are screened at once by a zero-byte test on word ^ literal.
+ * Does the compiled pattern (header hdr, body at word `at` of p) match
+ * s[0..len) ?  The anchored first segment is compared at position 0 (from the
+ * chunk after the index key on); every other segment is placed at its leftmost
+ * fit inside a window [lo, hi] of start positions (a single position for an
+ * anchored last segment).  When the segment starts with a literal, the four
+ * start positions covered by one string word are screened at once by a
+ * zero-byte test on word ^ literal.
  */
 template <class Prog, class Str>
-MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, const Str &s, uint32_t len, const uint32_t *sets)
+MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, uint32_t hdr, const Str &s, uint32_t len,
+                           const uint32_t *sets)
 {
-    const uint32_t hdr = p[at];
     const uint32_t minlen = MCX_HDR_MINLEN(hdr), flags = MCX_HDR_FLAGS(hdr), nseg = MCX_HDR_NSEG(hdr);
     if (flags & MCX_PF_NEVER)
         return false;
@@ -175,24 +279,26 @@ MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, const Str &s, uint32_t le
     if (!(flags & MCX_PF_HAS_STAR) && len != minlen)
         return false;
 
-    uint32_t w = at + 1u;
+    uint32_t w = at;
     uint32_t pos = 0;
     for (uint32_t k = 0; k < nseg; ++k) {
-        const uint32_t sh = p[w];
-        const uint32_t nchars = sh & 0xFFFFu, nsets = sh >> 16, nchunks = (nchars + 3u) >> 2;
-        const uint32_t chunks = w + 1u;
-        const uint32_t setlist = chunks + 2u * nchunks;
-        w = setlist + nsets;
-        if (nchars == 0u)
+        const mcx_seg_t g = mcx_seg_at(p, w, k, hdr);
+        w = g.next;
+        if (g.nchars == 0u)
             continue; /* only the anchored first segment can be empty */
-        if (pos + nchars > len)
+        if (pos + g.nchars > len)
             return false;
-        uint32_t lo = pos, hi = len - nchars;
-        if (k == 0u)
-            hi = 0u;
-        else if (k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR))
+        if (k == 0u) {
+            if (!mcx_seg_rest(p, g, g.c0, s, 0u, sets))
+                return false;
+            pos = g.nchars;
+            continue;
+        }
+        uint32_t lo = pos, hi = len - g.nchars;
+        if (k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR))
             lo = hi;
-        const uint32_t v0 = p[chunks], m0 = p[chunks + 1u];
+        uint32_t v0, m0;
+        mcx_chunk(p, g, 0u, v0, m0);
         /* first matcher a literal: its byte, repeated, for the screen */
         const bool lit0 = (m0 & 0xFFu) == 0xFFu;
         const uint32_t rep = (v0 & 0xFFu) * 0x01010101u;
@@ -213,8 +319,8 @@ MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, const Str &s, uint32_t le
                 const uint32_t win = d ? s.word(q + d) : w0;
                 if ((win ^ v0) & m0)
                     continue;
-                if (mcx_seg_rest(p, chunks, 1u, nchunks, setlist, nsets, s, q + d, sets)) {
-                    pos = q + d + nchars;
+                if (mcx_seg_rest(p, g, 1u, s, q + d, sets)) {
+                    pos = q + d + g.nchars;
                     found = true;
                 }
             }
@@ -227,103 +333,162 @@ MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, const Str &s, uint32_t le
 
 /*
  * The same decision for a string of at most 64 bytes, with its occurrence
- * table: occ[b] is the 64-bit set of positions q with s[q] == b.  Anchored
- * segments are compared word by word at their one position (the first one
- * from `skip` bytes on: the caller has already compared those).  For a
- * floating segment the start positions at which it fits are the AND over its
- * matchers k of (positions of that matcher's bytes) >> k, and placing it is a
- * find-first-set above the previous segment's end: no loop over string
- * positions, so lanes running different patterns stay together.
+ * table: occ[b] is the 64-bit set of positions q with s[q] == b.  The start
+ * positions at which a segment fits are the AND over its matchers k of
+ * (positions of that matcher's bytes) >> k: one 64-bit set per segment, which
+ * does not depend on the other segments, so the segments of a pattern can be
+ * evaluated by different lanes (mcx_seg_mask) and put together afterwards
+ * (mcx_step_*): the first segment must fit at 0, an anchored last one at
+ * len - nchars, every other one at its first fit at or after the end of the
+ * one before it.
  */
 #define MCX_OCC_MAX_LEN 64u
 
-template <class Prog, class Occ>
-MCX_HD uint64_t mcx_seg_fits(const Prog &p, uint32_t chunks, uint32_t nchars, uint32_t setlist, uint32_t nsets,
-                             const Occ &occ, uint64_t all, const uint32_t *sets)
+/* NEVER flag and the length conditions every matcher checks first */
+MCX_HD bool mcx_precheck(uint32_t hdr, uint32_t len)
 {
-    /* branch-free and one chunk ahead: the two words of chunk c+1 are requested
-     * before the four table reads of chunk c are combined (reads of a program
-     * word or two past the segment, and of table entry 0 for padding bytes, are
-     * harmless: their results are masked) */
-    const uint32_t nchunks = (nchars + 3u) >> 2;
-    uint64_t M = all;
-    uint32_t v = p[chunks], m = p[chunks + 1u];
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        const uint32_t vn = p[chunks + 2u * c + 2u], mn = p[chunks + 2u * c + 3u];
-        const uint64_t o0 = occ[v & 0xFFu], o1 = occ[(v >> 8) & 0xFFu];
-        const uint64_t o2 = occ[(v >> 16) & 0xFFu], o3 = occ[v >> 24];
-        const uint32_t k0 = 4u * c;
-        const uint32_t left = nchars - k0; /* matchers in this chunk and after */
-        const uint64_t c0 = (m & 0xFFu) ? o0 : all;
-        const uint64_t c1 = (m & 0xFF00u) ? o1 : all;
-        const uint64_t c2 = (m & 0xFF0000u) ? o2 : all;
-        const uint64_t c3 = (m & 0xFF000000u) ? o3 : all;
-        const uint64_t keep = ~(uint64_t)0;
-        M &= c0 >> k0; /* left >= 1 always */
-        M &= (left > 1u) ? (c1 >> ((k0 + 1u) & 63u)) : keep;
-        M &= (left > 2u) ? (c2 >> ((k0 + 2u) & 63u)) : keep;
-        M &= (left > 3u) ? (c3 >> ((k0 + 3u) & 63u)) : keep;
-        v = vn;
-        m = mn;
-    }
-    for (uint32_t e = 0; e < nsets; ++e) {
-        const uint32_t ent = p[setlist + e];
-        uint64_t cls = 0;
-        for (uint32_t wi = 0; wi < 8u; ++wi) {
-            uint32_t bits = sets[(ent >> 16) * 8u + wi];
-            while (bits) {
-                cls |= occ[wi * 32u + (uint32_t)__builtin_ctz(bits)];
-                bits &= bits - 1u;
-            }
-        }
-        M &= cls >> (ent & 0xFFFFu);
-    }
-    return M;
-}
-
-template <class Prog, class Str, class Occ>
-MCX_HD bool mcx_prog_match_occ(const Prog &p, uint32_t at, const Str &s, const Occ &occ, uint32_t len,
-                               uint32_t skip, const uint32_t *sets)
-{
-    const uint32_t hdr = p[at];
-    const uint32_t minlen = MCX_HDR_MINLEN(hdr), flags = MCX_HDR_FLAGS(hdr), nseg = MCX_HDR_NSEG(hdr);
+    const uint32_t minlen = MCX_HDR_MINLEN(hdr), flags = MCX_HDR_FLAGS(hdr);
     if (flags & MCX_PF_NEVER)
         return false;
     if (len < minlen)
         return false;
     if (!(flags & MCX_PF_HAS_STAR) && len != minlen)
         return false;
-    const uint64_t all = len >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << len) - 1u);
-
-    uint32_t w = at + 1u;
-    uint32_t pos = 0;
-    for (uint32_t k = 0; k < nseg; ++k) {
-        const uint32_t sh = p[w];
-        const uint32_t nchars = sh & 0xFFFFu, nsets = sh >> 16, nchunks = (nchars + 3u) >> 2;
-        const uint32_t chunks = w + 1u;
-        const uint32_t setlist = chunks + 2u * nchunks;
-        w = setlist + nsets;
-        if (nchars == 0u)
-            continue; /* only the anchored first segment can be empty */
-        if (pos + nchars > len)
-            return false;
-        if (k == 0u) {
-            if (!mcx_seg_rest(p, chunks, skip >> 2, nchunks, setlist, nsets, s, 0u, sets))
-                return false;
-            pos = nchars;
-        } else if (k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR)) {
-            if (!mcx_seg_rest(p, chunks, 0u, nchunks, setlist, nsets, s, len - nchars, sets))
-                return false;
-            pos = len;
-        } else {
-            uint64_t M = mcx_seg_fits(p, chunks, nchars, setlist, nsets, occ, all, sets);
-            M &= ~(uint64_t)0 << pos;
-            if (M == 0u)
-                return false;
-            pos = (uint32_t)__builtin_ctzll(M) + nchars;
-        }
-    }
     return true;
+}
+
+/* set of start positions at which segment g fits; chunks before g.c0 are the
+ * index key's and count as fitting */
+template <class Prog, class Occ>
+MCX_HD uint64_t mcx_seg_mask(const Prog &p, const mcx_seg_t &g, const Occ &occ, uint64_t all, const uint32_t *sets)
+{
+    /* branch-free and one chunk ahead: the words of chunk c+1 are requested
+     * before the four table reads of chunk c are combined (reads of a program
+     * word or two past the segment, and of table entry 0 for padding bytes, are
+     * harmless: their results are masked) */
+    uint64_t M = all;
+    uint32_t v, m;
+    mcx_chunk(p, g, g.c0, v, m);
+    for (uint32_t c = g.c0; c < g.nchunks; ++c) {
+        uint32_t vn, mn;
+        mcx_chunk(p, g, c + 1u, vn, mn);
+        const uint64_t o0 = occ[v & 0xFFu], o1 = occ[(v >> 8) & 0xFFu];
+        const uint64_t o2 = occ[(v >> 16) & 0xFFu], o3 = occ[v >> 24];
+        const uint32_t k0 = 4u * c;
+        const uint32_t left = g.nchars - k0; /* matchers in this chunk and after */
+        const uint64_t c0 = (m & 0xFFu) ? o0 : all;
+        const uint64_t c1 = (m & 0xFF00u) ? o1 : all;
+        const uint64_t c2 = (m & 0xFF0000u) ? o2 : all;
+        const uint64_t c3 = (m & 0xFF000000u) ? o3 : all;
+        const uint64_t keep = ~(uint64_t)0;
+        M &= c0 >> (k0 & 63u); /* left >= 1 always */
+        M &= (left > 1u) ? (c1 >> ((k0 + 1u) & 63u)) : keep;
+        M &= (left > 2u) ? (c2 >> ((k0 + 2u) & 63u)) : keep;
+        M &= (left > 3u) ? (c3 >> ((k0 + 3u) & 63u)) : keep;
+        v = vn;
+        m = mn;
+    }
+    for (uint32_t e = 0; e < g.nsets; ++e) {
+        const uint32_t at = g.setlist + MCX_SET_WORDS * e;
+        const uint32_t w0 = p[at], w1 = p[at + 1u], w2 = p[at + 2u], w3 = p[at + 3u];
+        const uint32_t n = w1 & 0xFFu;
+        uint64_t cls = 0; /* positions holding a byte of the set */
+        if (n != MCX_SET_GENERAL) {
+            for (uint32_t i = 0; i < n; ++i)
+                cls |= occ[mcx_set_member(w1, w2, w3, i)];
+            if ((w1 >> 8) & 1u)
+                cls = all & ~cls & ~occ[0u];
+        } else {
+            for (uint32_t wi = 0; wi < 8u; ++wi) {
+                uint32_t bits = sets[(w0 >> 16) * 8u + wi];
+                while (bits) {
+                    cls |= occ[wi * 32u + (uint32_t)__builtin_ctz(bits)];
+                    bits &= bits - 1u;
+                }
+            }
+        }
+        M &= cls >> ((w0 & 0xFFFFu) & 63u);
+    }
+    /* a segment longer than the string fits nowhere (its shifts wrapped) */
+    return g.nchars > 64u ? 0u : M;
+}
+
+/* slot word of the header of segment k < MCX_DIR_SEGS */
+template <class Prog>
+MCX_HD uint32_t mcx_dir_word(const Prog &slot, uint32_t k)
+{
+    return (slot[MCX_SLOT_DIR + (k >> 2)] >> (8u * (k & 3u))) & 0xFFu;
+}
+
+/*
+ * Putting the segments together is a chain over the segments in order.  Its
+ * state is {pos = where the next segment may start, ok}; one step places one
+ * segment.  What a step needs besides the state is fixed per segment
+ * (mcx_step_t), so on the device every lane prepares the step of its own
+ * segment and the state travels from lane to lane.
+ */
+#define MCX_STATE_START 0x100u /* pos 0, ok */
+#define MCX_STATE_OK(st) (((st) >> 8) & 1u)
+
+struct mcx_step_t {
+    uint64_t M;       /* fit set of the segment                                 */
+    uint64_t wantfix; /* anchored segments: the one start position allowed       */
+    uint32_t n;       /* segment length; 0 = nothing to place (state unchanged)  */
+    uint32_t anchored;
+};
+
+/* the step that leaves every state as it is */
+MCX_HD mcx_step_t mcx_step_none()
+{
+    mcx_step_t t;
+    t.M = 0;
+    t.wantfix = 0;
+    t.n = 0;
+    t.anchored = 0;
+    return t;
+}
+
+/* step of segment k < nseg with fit set M and length n */
+MCX_HD mcx_step_t mcx_step_make(uint32_t hdr, uint32_t len, uint32_t k, uint64_t M, uint32_t n)
+{
+    const uint32_t flags = MCX_HDR_FLAGS(hdr), nseg = MCX_HDR_NSEG(hdr);
+    mcx_step_t t;
+    t.M = M;
+    t.n = n; /* only the first segment can be empty */
+    const bool last_anchored = k == nseg - 1u && !(flags & MCX_PF_TRAIL_STAR);
+    t.anchored = (k == 0u || last_anchored) ? 1u : 0u;
+    t.wantfix = k == 0u ? (uint64_t)1 : ((uint64_t)1 << ((len - n) & 63u));
+    return t;
+}
+
+MCX_HD uint32_t mcx_step_apply(const mcx_step_t &t, uint32_t len, uint32_t state)
+{
+    const uint32_t pos = state & 0xFFu, ok = state >> 8;
+    const bool room = pos + t.n <= len; /* then pos <= 63 for n >= 1 */
+    const uint64_t want = t.anchored ? t.wantfix : (~(uint64_t)0 << (pos & 63u));
+    const uint64_t fit = t.M & want;
+    const bool nz = fit != 0u;
+    const uint32_t npos = (nz ? (uint32_t)__builtin_ctzll(fit) : 0u) + t.n;
+    const uint32_t nok = (room && nz) ? ok : 0u;
+    return t.n ? (npos | (nok << 8)) : state;
+}
+
+/* one caller doing all segments in turn: what the lanes of a group do together */
+template <class Prog, class Occ>
+MCX_HD bool mcx_slot_match_occ(const Prog &slot, const Occ &occ, uint32_t len, const uint32_t *sets)
+{
+    const uint32_t hdr = slot[0];
+    if (!mcx_precheck(hdr, len))
+        return false;
+    const uint64_t all = len >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << len) - 1u);
+    const uint32_t nseg = MCX_HDR_NSEG(hdr);
+    uint32_t state = MCX_STATE_START;
+    for (uint32_t k = 0; k < nseg; ++k) {
+        const mcx_seg_t g = mcx_seg_at(slot, mcx_dir_word(slot, k), k, hdr);
+        state = mcx_step_apply(mcx_step_make(hdr, len, k, mcx_seg_mask(slot, g, occ, all, sets), g.nchars), len,
+                               state);
+    }
+    return MCX_STATE_OK(state) != 0u;
 }
 
 #endif /* MCX_PROG_H */

@@ -37,18 +37,22 @@ struct HostOcc {
     uint64_t operator[](uint32_t b) const { return t[b]; }
 };
 
-/* the device's choice: occurrence-table matcher for strings of up to 64
- * bytes, position-loop matcher for longer ones */
-static bool match_like_device(const HostProg &hp, uint32_t at, const HostStr &s, uint32_t len,
-                              uint32_t skip, const uint32_t *sets)
+/* the device's choice: segment masks from the occurrence table for strings of
+ * up to 64 bytes whose pattern sits in its slot, position-loop matcher for
+ * longer strings and for bodies in the overflow array */
+static bool match_like_device(const uint32_t *slot, const uint32_t *ext, const HostStr &s, uint32_t len,
+                              const uint32_t *sets)
 {
+    const uint32_t hdr = slot[0];
+    if (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT)
+        return mcx_prog_match(HostProg{ext}, slot[MCX_SLOT_DIR], hdr, s, len, sets);
     if (len > MCX_OCC_MAX_LEN)
-        return mcx_prog_match(hp, at, s, len, sets);
+        return mcx_prog_match(HostProg{slot}, MCX_SLOT_BODY, hdr, s, len, sets);
     HostOcc occ;
     memset(&occ, 0, sizeof occ);
     for (uint32_t q = 0; q < len; ++q)
         occ.t[s.byte(q)] |= (uint64_t)1 << q;
-    return mcx_prog_match_occ(hp, at, s, occ, len, skip, sets);
+    return mcx_slot_match_occ(HostProg{slot}, occ, len, sets);
 }
 
 static void normalize(std::string &s, bool *bad)
@@ -92,14 +96,18 @@ int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t 
     int rc = mcx_parse_pattern((const uint8_t *)pattern, pn, false, t, ir, err);
     if (rc != 0)
         return rc;
-    std::vector<uint32_t> prog;
-    mcx_emit_program(ir, 0u, prog);
-    prog.insert(prog.end(), 4, 0u); /* read-ahead room */
+    uint32_t slot[MCX_SLOT_WORDS + 4] = {0}; /* read-ahead room */
+    std::vector<uint32_t> ext;
+    mcx_fill_slot(ir, 0u, 0u, t.sets, slot, ext);
+    ext.insert(ext.end(), 4, 0u);
     HostStr s{(const uint8_t *)string, sn};
-    HostProg hp{prog.data()};
     const uint32_t *sets = t.sets.empty() ? nullptr : t.sets.data();
-    int r = mcx_prog_match(hp, 0u, s, sn, sets) ? 1 : 0;
-    if (sn <= MCX_OCC_MAX_LEN && (match_like_device(hp, 0u, s, sn, 0u, sets) ? 1 : 0) != r)
+    const bool is_ext = (MCX_HDR_FLAGS(slot[0]) & MCX_PF_EXT) != 0;
+    int r = (is_ext ? mcx_prog_match(HostProg{ext.data()}, slot[MCX_SLOT_DIR], slot[0], s, sn, sets)
+                    : mcx_prog_match(HostProg{slot}, MCX_SLOT_BODY, slot[0], s, sn, sets))
+                ? 1
+                : 0;
+    if ((match_like_device(slot, ext.data(), s, sn, sets) ? 1 : 0) != r)
         return -100; /* the two matchers disagree */
     return r;
 }
@@ -146,19 +154,14 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
                     if (sl.h1 != a || sl.h2 != b || memcmp(sl.key, kw, sizeof kw) != 0)
                         continue;
                     for (uint32_t k = sl.start; k < sl.start + sl.count; ++k) {
-                        if (!mcx_sig_pass(t.sigorig[2 * (size_t)k], bloom))
+                        if (!mcx_sig_pass(t.sig[k], bloom))
                             continue;
                         const uint32_t *slot = &t.slot[(size_t)k * MCX_SLOT_WORDS];
-                        HostProg hp{slot};
-                        uint32_t at = 0;
-                        if (MCX_HDR_FLAGS(slot[0]) & MCX_PF_EXT) {
-                            hp.p = t.ext.data();
-                            at = slot[1];
-                        }
-                        /* the key's bytes were compared by the probe */
-                        if (match_like_device(hp, at, s, len, MCX_HDR_KEYLEN(slot[0]), sets)) {
-                            if (t.sigorig[2 * (size_t)k + 1] < first)
-                                first = t.sigorig[2 * (size_t)k + 1];
+                        /* the key's bytes were compared by the probe; the body
+                         * does not hold them */
+                        if (match_like_device(slot, t.ext.data(), s, len, sets)) {
+                            if (slot[1] < first)
+                                first = slot[1];
                             ++cnt;
                         }
                     }

@@ -96,6 +96,15 @@ def test_twin_vs_glibc_fuzz_ranges_and_high_bytes(oracle_mod):
     assert pairs > 40000
 
 
+def test_twin_vs_glibc_fuzz_long_patterns(oracle_mod):
+    # many '*' (more segments than a slot's directory names), long bodies (overflow
+    # array), segments longer than four chunks, strings on both sides of 64 bytes
+    pairs, matches, _ = _fuzz(oracle_mod, 4, 3000, b"a*?*[ab]", b"ab", 48, 90, 12)
+    assert pairs > 30000 and matches > 800
+    pairs, matches, _ = _fuzz(oracle_mod, 5, 3000, b"aaaaab*?", b"ab", 30, 70, 12)
+    assert pairs > 30000 and matches > 300
+
+
 # ---- kmod resolution fixture ---------------------------------------------------
 
 def test_oracle_reproduces_kmod_resolution(oracle_mod):
@@ -133,6 +142,37 @@ def test_twin_equals_oracle_on_synthetic(oracle_mod, seed, P, N):
     f2, c2 = oracle_mod.alias_match(A, a_off, S, s_off, use_twin=True)
     assert np.array_equal(f, f2) and np.array_equal(c, c2)
     assert (c > 0).mean() > 0.6  # 70 % of the strings are instances of a table pattern
+
+
+def prefix_heavy_table(rng, n_pat, n_str):
+    """patterns that share literal prefixes of every length 0..40 and go on with
+    literals, '?', brackets and '*' right after them (what the index key and the
+    key-less program bodies have to get right), and strings cut from the same cloth"""
+    stems = [bytes(rng.choice(list(b"abc01:")) for _ in range(44)) for _ in range(3)]
+    tails = [b"", b"*", b"?", b"x", b"[ab]", b"??*", b"*z", b"[!a]c*", b"a?c", b"\\*b", b"*[0-9]*", b"abcde*",
+             b"?bcd", b"[a-c][a-c]*", b"*ab*ab", b"ab?d*f"]
+    pats, strs = [], []
+    for _ in range(n_pat):
+        st = stems[rng.integers(0, 3)]
+        pats.append(st[: rng.integers(0, 41)] + tails[rng.integers(0, len(tails))])
+    fill = list(b"abc01:xz")
+    for _ in range(n_str):
+        st = stems[rng.integers(0, 3)]
+        k = rng.integers(0, 44)
+        strs.append(st[:k] + bytes(rng.choice(fill) for _ in range(rng.integers(0, 7))))
+    return pats, strs
+
+
+def test_twin_equals_oracle_on_prefix_heavy_tables(oracle_mod):
+    rng = np.random.default_rng(77)
+    for _ in range(3):
+        pats, strs = prefix_heavy_table(rng, 400, 300)
+        A, a_off = pack_strings(pats)
+        S, s_off = pack_strings(strs)
+        f, c = oracle_mod.alias_match(A, a_off, S, s_off)
+        f2, c2 = oracle_mod.alias_match(A, a_off, S, s_off, use_twin=True)
+        assert np.array_equal(f, f2) and np.array_equal(c, c2)
+        assert (c > 0).sum() > 30
 
 
 def test_generators_are_deterministic_and_shardable():
