@@ -23,6 +23,7 @@
 #include <array>
 #include <map>
 #include <string.h>
+#include <unordered_map>
 
 #include "../../include/mcx.h"
 
@@ -407,14 +408,15 @@ void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, const std::vect
     }
 }
 
-void mcx_fill_slot(const mcx_pattern_ir &ir, uint32_t keylen, uint32_t orig, const std::vector<uint32_t> &sets,
-                   uint32_t *slot, std::vector<uint32_t> &ext)
+void mcx_fill_slot(const mcx_pattern_ir &ir, uint32_t keylen, uint32_t orig, uint32_t mult,
+                   const std::vector<uint32_t> &sets, uint32_t *slot, std::vector<uint32_t> &ext)
 {
     std::vector<uint32_t> one, seg_words;
     mcx_emit_program(ir, keylen, sets, one, &seg_words);
     std::fill(slot, slot + MCX_SLOT_WORDS, 0u);
     slot[0] = one[0];
     slot[1] = orig;
+    slot[MCX_SLOT_MULT] = mult;
     const size_t body = one.size() - 1;
     if (ir.segs.size() <= MCX_DIR_SEGS && body <= MCX_SLOT_WORDS - MCX_SLOT_BODY) {
         for (size_t k = 0; k < seg_words.size(); ++k) /* word of `one` -> word of the slot */
@@ -483,8 +485,11 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     out.hw_tag.resize(P);
     std::vector<mcx_pattern_ir> irs(P);
     std::vector<std::string> keys(P);
-    std::vector<uint32_t> order;
+    std::vector<uint32_t> order, mult(P, 0u);
     order.reserve(P);
+    /* patterns with the same text are indexed once, under their first position */
+    std::unordered_map<std::string, uint32_t> seen;
+    seen.reserve(P);
     for (uint32_t j = 0; j < P; ++j) {
         if (a_off[j + 1] < a_off[j]) {
             err = "a_off not monotonic at pattern " + std::to_string(j);
@@ -492,13 +497,20 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         }
         const uint8_t *pat = (const uint8_t *)arena + a_off[j];
         size_t n = (size_t)(a_off[j + 1] - a_off[j]);
+        out.hw_tag[j] = hw_tag_of(pat, n);
+        auto ins = seen.emplace(std::string((const char *)pat, n), j);
+        if (!ins.second) {
+            /* a repeat: parsed (and, if need be, refused) when first seen */
+            if (mult[ins.first->second])
+                mult[ins.first->second]++;
+            continue;
+        }
         std::string e;
         int rc = mcx_parse_pattern(pat, n, normalize_dash, out, irs[j], e);
         if (rc != 0) {
             err = "pattern " + std::to_string(j) + ": " + e;
             return rc;
         }
-        out.hw_tag[j] = hw_tag_of(pat, n);
         if (nseg_too_long(irs[j])) {
             err = "pattern " + std::to_string(j) + ": segment longer than 65535 bytes";
             return MCX_E_PATTERN;
@@ -506,6 +518,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         if (irs[j].flags & MCX_PF_NEVER)
             continue; /* matches nothing: never a candidate */
         keys[j] = key_of(irs[j]);
+        mult[j] = 1;
         order.push_back(j);
     }
     /* index order: by key length, then key bytes, then table position */
@@ -518,6 +531,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         return x < y;
     });
     size_t n_idx = order.size();
+    out.n_distinct = (uint32_t)n_idx;
     out.slot.assign(n_idx * (size_t)MCX_SLOT_WORDS, 0u);
     out.sig.resize(n_idx);
     struct Group {
@@ -532,8 +546,8 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
                 out.lens.push_back((uint32_t)keys[j].size());
         }
         groups.back().count++;
-        mcx_fill_slot(irs[j], (uint32_t)keys[j].size(), j, out.sets, &out.slot[k * (size_t)MCX_SLOT_WORDS],
-                      out.ext);
+        mcx_fill_slot(irs[j], (uint32_t)keys[j].size(), j, mult[j], out.sets,
+                      &out.slot[k * (size_t)MCX_SLOT_WORDS], out.ext);
         out.sig[k] = sig_of(irs[j], keys[j].size());
     }
     /* the matchers read up to two words past a program, the screen up to three

@@ -30,7 +30,8 @@ struct mcx_pattern_ir {
 
 struct mcx_compiled_table {
     uint32_t P = 0;                  /* patterns in the source table          */
-    std::vector<uint32_t> slot;      /* n_indexed x MCX_SLOT_WORDS, index order */
+    uint32_t n_distinct = 0;         /* distinct pattern texts that can match  */
+    std::vector<uint32_t> slot;      /* n_distinct x MCX_SLOT_WORDS, index order */
     std::vector<uint32_t> ext;       /* programs too long for a slot          */
     std::vector<uint32_t> sig;       /* n_indexed gram signatures, index order */
     std::vector<mcx_slot_t> slots;   /* open-addressing hash table, 2^k slots */
@@ -55,9 +56,10 @@ void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, const std::vect
                       std::vector<uint32_t> &prog, std::vector<uint32_t> *seg_words = nullptr);
 
 /* Fill the MCX_SLOT_WORDS words of one pattern's slot (orig = its position in
- * the caller's table); a body the slot cannot hold is appended to ext. */
-void mcx_fill_slot(const mcx_pattern_ir &ir, uint32_t keylen, uint32_t orig, const std::vector<uint32_t> &sets,
-                   uint32_t *slot, std::vector<uint32_t> &ext);
+ * the caller's table, mult = how many table patterns have this text); a body
+ * the slot cannot hold is appended to ext. */
+void mcx_fill_slot(const mcx_pattern_ir &ir, uint32_t keylen, uint32_t orig, uint32_t mult,
+                   const std::vector<uint32_t> &sets, uint32_t *slot, std::vector<uint32_t> &ext);
 
 /* Whole table: parse, group by literal prefix, emit programs in group order
  * and build the hash index. */

@@ -386,7 +386,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             }
             if (ok) {
                 atomicMin(&res_first[slot], sp[1]);
-                atomicAdd(&res_count[slot], 1u);
+                atomicAdd(&res_count[slot], sp[MCX_SLOT_MULT]);
             }
         }
     };
@@ -469,7 +469,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             }
             if (ok) {
                 atomicMin(&res_first[slot], lp[1]);
-                atomicAdd(&res_count[slot], 1u);
+                atomicAdd(&res_count[slot], lp[MCX_SLOT_MULT]);
             }
             K1_TOCK(acc_comb);
 #ifdef MCX_K1_STAMPS
@@ -661,7 +661,7 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->P = P;
-    ctx->n_indexed = (uint32_t)t.sig.size() - 4u; /* the array ends in four words of padding */
+    ctx->n_indexed = t.n_distinct;
     ctx->slot_mask = (uint32_t)t.slots.size() - 1u;
     ctx->nlens = (uint32_t)t.lens.size();
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;

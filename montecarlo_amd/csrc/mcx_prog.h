@@ -35,8 +35,11 @@
  *     0..23) | nchars (24..25) | which bytes are literals (26..28) | inline (30).
  *
  * Storage: every indexed pattern owns one slot of MCX_SLOT_WORDS words:
- *   {header, position of the pattern in the caller's table, four words of
- *    segment directory, body ...}
+ *   {header, position of the pattern in the caller's table, multiplicity,
+ *    four words of segment directory, body ...}
+ * Patterns with the same text share one slot: its position is the smallest of
+ * theirs and its multiplicity their number, which is all that first-match and
+ * match-count need.
  * The directory holds, one byte each, the slot word at which the header of
  * segment 0..15 sits, so that the segments of one pattern can be evaluated by
  * different lanes.  A pattern with more than sixteen segments or a body that
@@ -77,8 +80,9 @@
 #define MCX_PF_EXT        8u   /* slot holds {header, overflow offset} only */
 
 #define MCX_SLOT_WORDS    32u
-#define MCX_SLOT_DIR      2u   /* segment directory word of a slot */
-#define MCX_SLOT_BODY     6u   /* first body word of a slot */
+#define MCX_SLOT_MULT     2u   /* number of table patterns with this text */
+#define MCX_SLOT_DIR      3u   /* first segment directory word of a slot */
+#define MCX_SLOT_BODY     7u   /* first body word of a slot */
 #define MCX_DIR_SEGS      16u  /* segments the directory can name */
 #define MCX_SEG_MASKED     0x80000000u
 #define MCX_SEG_INLINE     0x40000000u

@@ -98,7 +98,7 @@ int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t 
         return rc;
     uint32_t slot[MCX_SLOT_WORDS + 4] = {0}; /* read-ahead room */
     std::vector<uint32_t> ext;
-    mcx_fill_slot(ir, 0u, 0u, t.sets, slot, ext);
+    mcx_fill_slot(ir, 0u, 0u, 1u, t.sets, slot, ext);
     ext.insert(ext.end(), 4, 0u);
     HostStr s{(const uint8_t *)string, sn};
     const uint32_t *sets = t.sets.empty() ? nullptr : t.sets.data();
@@ -162,7 +162,7 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
                         if (match_like_device(slot, t.ext.data(), s, len, sets)) {
                             if (slot[1] < first)
                                 first = slot[1];
-                            ++cnt;
+                            cnt += slot[MCX_SLOT_MULT];
                         }
                     }
                     break;
