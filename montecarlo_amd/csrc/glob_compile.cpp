@@ -555,20 +555,23 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     out.sig.insert(out.sig.end(), 4, 0u);
     out.slot.insert(out.slot.end(), 4, 0u);
     out.ext.insert(out.ext.end(), 4, 0u);
-    /* hash table: at least twice as many slots as groups, never empty */
+    /* hash table, never empty.  A probe that meets an occupied slot costs one
+     * more dependent load, so the table is kept sparse (one slot in eight
+     * used) as long as that is cheap, and half empty beyond */
     size_t cap = 16;
-    while (cap < 8 * groups.size())
+    const size_t spread = groups.size() <= ((size_t)1 << 17) ? 8 : 2;
+    while (cap < spread * groups.size())
         cap *= 2;
     out.slots.assign(cap, mcx_slot_t{0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}});
     for (const Group &g : groups) {
         const std::string &key = keys[order[g.start]];
-        uint32_t a, b, kw[MCX_KEY_MAX / 4] = {0};
+        uint32_t kw[MCX_KEY_MAX / 4] = {0};
         memcpy(kw, key.data(), key.size());
-        mcx_key_hash(kw, (uint32_t)key.size(), a, b);
+        const uint32_t a = mcx_key_hash(kw, (uint32_t)key.size());
         size_t at = a & (cap - 1);
         while (out.slots[at].count != 0)
             at = (at + 1) & (cap - 1);
-        mcx_slot_t sl = mcx_slot_t{a, b, g.start, g.count, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}};
+        mcx_slot_t sl = mcx_slot_t{a, (uint32_t)key.size(), g.start, g.count, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}};
         memcpy(sl.key, kw, sizeof kw);
         out.slots[at] = sl;
     }

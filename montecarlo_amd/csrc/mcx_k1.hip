@@ -272,8 +272,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
             if ((L >> 2) == k && (L & 3u))
                 kw[k] &= 0xFFFFFFFFu >> (8u * (4u - (L & 3u)));
-        uint32_t a, b;
-        mcx_key_hash(kw, L, a, b);
+        const uint32_t a = mcx_key_hash(kw, L);
 #ifdef MCX_K1_STAMPS
         pt1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -281,7 +280,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             const mcx_slot_t sl = T.slots[at];
             if (sl.count == 0u)
                 break;
-            bool same = sl.h1 == a && sl.h2 == b;
+            bool same = sl.hash == a && sl.len == L;
 #pragma unroll
             for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
                 same = same && sl.key[k] == kw[k];
@@ -325,11 +324,11 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         const unsigned long long m = __ballot(u - my_ub < my_units); /* lanes without a hit: 0 units */
         uint32_t ub, cnt, start;
         if (m) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(m);
-            ub = __shfl(my_ub, src, 64);
-            cnt = __shfl(my_cnt, src, 64);
-            start = __shfl(my_start, src, 64);
-            slot = __shfl(my_slot, src, 64);
+            const uint32_t src = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(m));
+            ub = __builtin_amdgcn_readlane(my_ub, src);
+            cnt = __builtin_amdgcn_readlane(my_cnt, src);
+            start = __builtin_amdgcn_readlane(my_start, src);
+            slot = __builtin_amdgcn_readlane(my_slot, src);
         } else {
             /* more than 64 hits in the block: the rest is searched in LDS */
             uint32_t h = 64u;
@@ -516,32 +515,31 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         if (u < nunits) {
             LdsBloom bl{(lds_words_t)bloom[slot]};
             bool pass[4];
-            uint32_t npass = 0;
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4; ++jj)
+                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj], bl);
+            /* one reservation per wave; the order of the survivors in the ring
+             * does not matter, so every one of the four pattern columns is
+             * compacted by its own ballot */
+            unsigned long long bm[4];
+            uint32_t col[4], wtotal = 0;
 #pragma unroll
             for (uint32_t jj = 0; jj < 4; ++jj) {
-                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj], bl);
-                npass += pass[jj] ? 1u : 0u;
+                bm[jj] = __ballot(pass[jj]);
+                col[jj] = wtotal;
+                wtotal += (uint32_t)__popcll(bm[jj]);
             }
-            /* wave-wide exclusive scan of npass, one reservation per wave */
-            uint32_t incl = npass;
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) {
-                uint32_t o = __shfl_up(incl, d, 64);
-                if (lane >= d)
-                    incl += o;
-            }
-            const uint32_t wtotal = __shfl(incl, 63, 64);
             if (wtotal) {
                 uint32_t base = 0;
                 if (lane == 0)
                     base = atomicAdd(&ring_cum[r & 1u], wtotal);
-                base = tail + (__shfl(base, 0, 64) - ((r & 1u) ? seen1 : seen0));
-                uint32_t at = base + incl - npass;
+                base = tail + (__builtin_amdgcn_readfirstlane(base) - ((r & 1u) ? seen1 : seen0));
 #pragma unroll
                 for (uint32_t jj = 0; jj < 4; ++jj)
                     if (pass[jj]) {
-                        ring[at & (K1_RING - 1u)] = (slot << 26) | (k0 + 4u * lane + jj);
-                        ++at;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(bm[jj] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[jj], 0u));
+                        ring[(base + col[jj] + rank) & (K1_RING - 1u)] = (slot << 26) | (k0 + 4u * lane + jj);
                     }
             }
         }
@@ -575,13 +573,21 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     K1_STAMP(4);
     {
-        /* fewer than K1_WAVES groups are left: split them over the waves, a
-         * wave's time follows its slowest lane, not its lane count */
+        /* what is left goes to as few waves as the passes allow: a pass costs
+         * a wave the same whatever its number of live lanes, so the survivors
+         * are dealt out in whole passes (eight groups of lanes, or 64 lanes)
+         * and a wave without one stays out of the way of the other blocks'
+         * waves on its SIMD */
+        constexpr uint32_t PASS = BULK ? 64u : K1_SUB;
         const uint32_t avail = tail - head;
-        const uint32_t share = (avail + K1_WAVES - 1u) / K1_WAVES;
+        const uint32_t passes = (avail + PASS - 1u) / PASS;
+        const uint32_t share = PASS * ((passes + K1_WAVES - 1u) / K1_WAVES);
         const uint32_t from = wave * share;
-        if (from < avail)
-            run_survivors(head + from, min(share, avail - from));
+        if (from < avail) {
+            const uint32_t mine = min(share, avail - from);
+            for (uint32_t off = 0; off < mine; off += GROUP)
+                run_survivors(head + from + off, min(GROUP, mine - off));
+        }
     }
     __syncthreads();
     K1_STAMP(5);
@@ -707,11 +713,6 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     uint32_t spb = (N + 2047u) / 2048u;
     if (spb > K1_MAX_SPB)
         spb = K1_MAX_SPB;
-    if (const char *e = getenv("MCX_K1_SPB_TRY")) { /* TEMP experiment */
-        uint32_t v = (uint32_t)atoi(e);
-        if (v >= 1 && v <= K1_MAX_SPB)
-            spb = v;
-    }
     uint32_t blocks = (N + spb - 1u) / spb;
     k1_table_t T;
     T.slot = ctx->d_slot;
@@ -739,11 +740,10 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     k1_match_indexed<false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
                                                                       d_first, d_count, g_k1_stamps);
 #else
-    /* a block with one or two strings is latency bound: eight lanes per
-     * survivor; more strings give the waves full groups: a lane per survivor */
-    bool bulk = spb > 2u;
-    if (const char *e = getenv("MCX_K1_BULK_TRY")) /* TEMP experiment */
-        bulk = atoi(e) != 0;
+    /* eight lanes per survivor while a block's waves see few survivors at a
+     * time; a lane per survivor once every pass fills its wave (measured: the
+     * two meet at about 10^5 strings against 3 x 10^4 patterns) */
+    const bool bulk = N >= 65536u;
     if (bulk)
         k1_match_indexed<true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned,
                                                                          T, d_first, d_count);

@@ -108,33 +108,31 @@
 #define MCX_HDR_NSEG(w) ((w) >> 24)
 
 /* one slot of the prefix index: a group of patterns that share the literal
- * prefix of length len whose hash is (h1, h2); empty when count == 0 */
+ * prefix `key`; empty when count == 0.  64 bytes, so that a slot never
+ * straddles a cache line. */
 typedef struct {
-    uint32_t h1, h2;
-    uint32_t start; /* first pattern of the group, in index order */
+    uint32_t hash;   /* mcx_key_hash of the key: a cheap first compare */
+    uint32_t len;    /* key length in bytes */
+    uint32_t start;  /* first pattern of the group, in index order */
     uint32_t count;
     uint32_t key[8]; /* the literal prefix itself, zero padded */
-    uint32_t pad[4]; /* 64 bytes: a slot never straddles a cache line */
+    uint32_t pad[4];
 } mcx_slot_t;
 
 /* Hash of a key of `len` <= MCX_KEY_MAX bytes held in little-endian words
- * kw[0..7] (bytes past `len` must be zero). */
-MCX_HD void mcx_key_hash(const uint32_t *kw, uint32_t len, uint32_t &a, uint32_t &b)
+ * kw[0..7] (bytes past `len` must be zero).  It only spreads the keys over the
+ * table: a probe compares the key itself. */
+MCX_HD uint32_t mcx_key_hash(const uint32_t *kw, uint32_t len)
 {
-    a = 0x811C9DC5u ^ (len * 0x9E3779B1u);
-    b = 0x9747B28Cu + len;
+    uint32_t a = 0x811C9DC5u ^ (len * 0x9E3779B1u);
     MCX_UNROLL
     for (uint32_t k = 0; k < MCX_KEY_MAX / 4u; ++k) {
-        uint32_t w = (4u * k < len) ? kw[k] : 0u;
-        a = (a ^ w) * 0x01000193u;
+        a = (a ^ kw[k]) * 0x01000193u;
         a ^= a >> 15;
-        b = (b + w) * 0x85EBCA6Bu;
-        b ^= b >> 13;
     }
     a *= 0x7FEB352Du;
     a ^= a >> 16;
-    b *= 0xC2B2AE35u;
-    b ^= b >> 16;
+    return a;
 }
 
 /* Bloom bit (0..254) of the gram whose four bytes form the word g */

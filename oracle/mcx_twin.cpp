@@ -145,13 +145,13 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
             for (uint32_t L : t.lens) {
                 if (L > len)
                     continue;
-                uint32_t a, b, kw[MCX_KEY_MAX / 4] = {0};
+                uint32_t kw[MCX_KEY_MAX / 4] = {0};
                 for (uint32_t k = 0; k < L; ++k)
                     kw[k >> 2] |= s.byte(k) << (8u * (k & 3u));
-                mcx_key_hash(kw, L, a, b);
+                const uint32_t a = mcx_key_hash(kw, L);
                 for (size_t at = a & mask; t.slots[at].count != 0; at = (at + 1) & mask) {
                     const mcx_slot_t &sl = t.slots[at];
-                    if (sl.h1 != a || sl.h2 != b || memcmp(sl.key, kw, sizeof kw) != 0)
+                    if (sl.hash != a || sl.len != L || memcmp(sl.key, kw, sizeof kw) != 0)
                         continue;
                     for (uint32_t k = sl.start; k < sl.start + sl.count; ++k) {
                         if (!mcx_sig_pass(t.sig[k], bloom))
