@@ -43,20 +43,48 @@ __device__ __forceinline__ void fl_set(uint32_t *M, uint32_t HW, uint32_t m, uin
         atomicOr(w, bit);
 }
 
-/* one thread per device: U[driver module][host] */
+/*
+ * One thread per device: U[driver module][host].  The devices of a block are
+ * consecutive, so they belong to a short run of hosts: the block finds the
+ * host of its first device once, copies that run of dev_off into LDS and every
+ * thread searches there.
+ */
 __global__ void __launch_bounds__(FL_THREADS)
 fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restrict__ a_mod, uint32_t N,
                 const uint32_t *__restrict__ dev_off, uint32_t H, uint32_t V, uint32_t HW, uint32_t *U)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t run[FL_THREADS + 1]; /* dev_off[h0 .. h0 + FL_THREADS] */
+    const uint32_t i0 = blockIdx.x * FL_THREADS;
+    const uint32_t i = i0 + threadIdx.x;
+    const uint32_t h0 = fl_owner(dev_off, H, i0);
+    for (uint32_t k = threadIdx.x; k <= FL_THREADS; k += FL_THREADS)
+        run[k] = h0 + k <= H ? dev_off[h0 + k] : 0xFFFFFFFFu;
+    __syncthreads();
     if (i >= N)
         return;
     const uint32_t j = first_idx[i];
     if (j == MCX_NO_MATCH)
         return;
     const uint32_t m = a_mod[j];
-    if (m < V)
-        fl_set(U, HW, m, fl_owner(dev_off, H, i));
+    if (m >= V)
+        return;
+    /* largest k with run[k] <= i; beyond the copied run (256 hosts without a
+     * device in a row) the search goes back to the whole array */
+    uint32_t h;
+    if (run[FL_THREADS] <= i) {
+        h = fl_owner(dev_off, H, i);
+    } else {
+        uint32_t lo = 0, hi = FL_THREADS;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (run[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        h = h0 + lo;
+    }
+    fl_set(U, HW, m, h);
 }
 
 /* one thread per entry of the hosts' extra-module lists: L[module][host] */
@@ -99,34 +127,56 @@ fl_level(const uint32_t *__restrict__ order, uint32_t n_rows, const uint32_t *__
     U[at] = (safe_name[v] && hw_alias[v]) ? (loaded & ~used & ~hold) : 0u;
 }
 
-/* one thread per host: walk the host's bit column of R in module order */
-__global__ void __launch_bounds__(FL_THREADS)
-fl_count(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, uint32_t *__restrict__ cnt)
+/*
+ * R -> per-host lists.  One thread per word column of R (32 hosts), walking the
+ * modules in ascending order, so that every host's list comes out sorted and
+ * R is read exactly once, coalesced (the set bits are sparse: the inner loop
+ * rarely runs).  Each thread keeps its 32 list cursors in LDS.  FILL = false
+ * counts (cnt[h] = entries of host h), FILL = true writes the module ids to
+ * root_ids starting at root_off[h].
+ */
+#define FLC_THREADS 64
+template <bool FILL>
+__global__ void __launch_bounds__(FLC_THREADS)
+fl_columns(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, uint32_t *__restrict__ cnt,
+           const uint32_t *__restrict__ root_off, uint32_t *__restrict__ root_ids)
 {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H)
+    __shared__ uint32_t cur[32][FLC_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t w = blockIdx.x * FLC_THREADS + tid;
+    if (w >= HW)
         return;
-    const uint32_t *colw = R + (h >> 5);
-    const uint32_t sh = h & 31u;
-    uint32_t n = 0;
-    for (uint32_t v = 0; v < V; ++v)
-        n += (colw[(size_t)v * HW] >> sh) & 1u;
-    cnt[h] = n;
-}
-
-__global__ void __launch_bounds__(FL_THREADS)
-fl_fill(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW,
-        const uint32_t *__restrict__ root_off, uint32_t *__restrict__ root_ids)
-{
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H)
-        return;
-    const uint32_t *colw = R + (h >> 5);
-    const uint32_t sh = h & 31u;
-    uint32_t at = root_off[h];
-    for (uint32_t v = 0; v < V; ++v)
-        if ((colw[(size_t)v * HW] >> sh) & 1u)
-            root_ids[at++] = v;
+#pragma unroll
+    for (uint32_t b = 0; b < 32u; ++b) {
+        const uint32_t h = 32u * w + b;
+        cur[b][tid] = (FILL && h < H) ? root_off[h] : 0u;
+    }
+    const uint32_t *col = R + w;
+    for (uint32_t v0 = 0; v0 < V; v0 += 8u) {
+        uint32_t r[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            r[k] = v0 + k < V ? col[(size_t)(v0 + k) * HW] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            uint32_t bits = r[k];
+            while (bits) {
+                const uint32_t b = (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+                const uint32_t at = cur[b][tid]++;
+                if (FILL)
+                    root_ids[at] = v0 + k;
+            }
+        }
+    }
+    if (!FILL) {
+#pragma unroll
+        for (uint32_t b = 0; b < 32u; ++b) {
+            const uint32_t h = 32u * w + b;
+            if (h < H)
+                cnt[h] = cur[b][tid];
+        }
+    }
 }
 
 /* ---- exclusive scan of H counts into H + 1 offsets ------------------------ */
@@ -308,7 +358,8 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
                                                                   ctx->d_rcol, (const uint8_t *)d_safe_name, d_hw,
                                                                   HW, U, L);
     }
-    fl_count<<<(H + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_cnt);
+    fl_columns<false><<<(HW + FLC_THREADS - 1) / FLC_THREADS, FLC_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_cnt,
+                                                                                             nullptr, nullptr);
     fl_scan_sums<<<nb, FL_THREADS, 0, ctx->stream>>>(d_cnt, H, d_bsum);
     fl_scan_top<<<1, FL_THREADS, 0, ctx->stream>>>(d_bsum, nb, d_total);
     fl_scan_apply<<<nb, FL_THREADS, 0, ctx->stream>>>(d_cnt, H, d_bsum, (uint32_t *)d_root_off);
@@ -326,8 +377,8 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
         return MCX_E_TOO_LARGE;
     }
     if (*h_total)
-        fl_fill<<<(H + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
-            U, V, H, HW, (const uint32_t *)d_root_off, (uint32_t *)d_root_ids);
+        fl_columns<true><<<(HW + FLC_THREADS - 1) / FLC_THREADS, FLC_THREADS, 0, ctx->stream>>>(
+            U, V, H, HW, nullptr, (const uint32_t *)d_root_off, (uint32_t *)d_root_ids);
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
 }
