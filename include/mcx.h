@@ -222,6 +222,56 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
                         void *d_root_off, void *d_root_ids, uint64_t cap,
                         uint64_t *total_out);
 
+/* ---- text tables: modules.alias, modules.dep, /proc/modules ------------- */
+
+/*
+ * The reference leaves these files to kmod (modprobe at
+ * montecarlo/libmontecarlo.c:123, `modinfo -F alias` at desktop/ui.py:1527)
+ * and reads /proc/modules token by token
+ * (montecarlo/libmontecarlo.c:499-532).  A mcx_modtab parses their text into
+ * the arrays the entry points above take.  Module ids are handed out in order
+ * of first appearance, over all texts added to one table; a module's name is
+ * the base name of its file up to the first '.', with '-' written as '_'
+ * (the rule at desktop/ui.py:481-482).  Host only, no context needed.
+ */
+typedef struct mcx_modtab mcx_modtab;
+
+mcx_modtab *mcx_modtab_create(void);
+void mcx_modtab_destroy(mcx_modtab *t);
+const char *mcx_modtab_last_error(mcx_modtab *t);
+/* "alias <glob> <module>" lines; '#' comments, blank lines and lines with
+ * other keywords are skipped.  Patterns keep file order. */
+int mcx_modtab_add_alias_text(mcx_modtab *t, const char *text, size_t len);
+/* "<path>.ko[.xz|.zst|.gz]: <dep path> ..." lines: everything the module needs,
+ * directly or not, as depmod writes it. */
+int mcx_modtab_add_dep_text(mcx_modtab *t, const char *text, size_t len);
+/* both files of one /lib/modules/<version> directory */
+int mcx_modtab_load_dir(mcx_modtab *t, const char *dir);
+int mcx_modtab_counts(mcx_modtab *t, uint32_t *patterns, uint32_t *modules, uint64_t *alias_bytes);
+/* the alias table as mcx_alias_table_load takes it; pointers stay valid until
+ * the table is added to or destroyed */
+int mcx_modtab_alias_arrays(mcx_modtab *t, const char **arena, const uint32_t **a_off,
+                            const uint32_t **a_mod);
+/* dependency CSR over module ids, rows sorted.  direct = 0: the lists as the
+ * file has them (transitive); direct = 1: without the entries another entry of
+ * the same list already needs, i.e. the edges /sys/module/<m>/holders shows and
+ * mcx_dep_graph_load wants. */
+int mcx_modtab_dep_arrays(mcx_modtab *t, int direct, const uint32_t **rowptr, const uint32_t **col,
+                          uint32_t *edges);
+const char *mcx_modtab_module_name(mcx_modtab *t, uint32_t id);   /* NULL if out of range */
+uint32_t mcx_modtab_module_id(mcx_modtab *t, const char *name);    /* MCX_NO_MATCH if unknown */
+/* all names packed for mcx_safe_module_names: name_off needs modules + 1
+ * entries; call with names = NULL to get the size in *bytes_out */
+int mcx_modtab_module_names(mcx_modtab *t, char *names, uint64_t cap, uint32_t *name_off,
+                            uint64_t *bytes_out);
+/* /proc/modules text: in_flags[id] |= MCX_F_LOADED for every first token that
+ * names a module of the table; *unknown counts the ones that do not */
+int mcx_modtab_mark_loaded(mcx_modtab *t, const char *proc_modules, size_t len, uint8_t *in_flags,
+                           uint32_t *unknown);
+/* mcx_alias_table_load / mcx_dep_graph_load (direct edges) from a table */
+int mcx_alias_table_load_modtab(mcx_ctx *ctx, mcx_modtab *t, uint32_t flags);
+int mcx_dep_graph_load_modtab(mcx_ctx *ctx, mcx_modtab *t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@ fallback: without the built library or without a HIP device every call raises.
 from .binding import (  # noqa: F401
     McxError,
     Context,
+    ModTab,
     load_library,
     library_path,
     NO_MATCH,

@@ -82,6 +82,30 @@ def load_library():
             ctypes.c_int,
             [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)],
         ),
+        "mcx_modtab_create": (_vp, []),
+        "mcx_modtab_destroy": (None, [_vp]),
+        "mcx_modtab_last_error": (ctypes.c_char_p, [_vp]),
+        "mcx_modtab_add_alias_text": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+        "mcx_modtab_add_dep_text": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+        "mcx_modtab_load_dir": (ctypes.c_int, [_vp, ctypes.c_char_p]),
+        "mcx_modtab_counts": (
+            ctypes.c_int,
+            [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_modtab_alias_arrays": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+        "mcx_modtab_dep_arrays": (
+            ctypes.c_int,
+            [_vp, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32)],
+        ),
+        "mcx_modtab_module_name": (ctypes.c_char_p, [_vp, ctypes.c_uint32]),
+        "mcx_modtab_module_id": (ctypes.c_uint32, [_vp, ctypes.c_char_p]),
+        "mcx_modtab_module_names": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, _vp, ctypes.POINTER(ctypes.c_uint64)]),
+        "mcx_modtab_mark_loaded": (
+            ctypes.c_int,
+            [_vp, ctypes.c_char_p, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_uint32)],
+        ),
+        "mcx_alias_table_load_modtab": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32]),
+        "mcx_dep_graph_load_modtab": (ctypes.c_int, [_vp, _vp]),
         "mcx_safe_module_names": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
         "mcx_safe_table_sizes": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
         "mcx_fleet_roots": (
@@ -299,6 +323,15 @@ class Context:
         )
         return edges.value, levels.value
 
+    def alias_table_load_modtab(self, tab, flags=0):
+        self._check(self.lib.mcx_alias_table_load_modtab(self.h, tab.h, flags), "mcx_alias_table_load_modtab")
+        self.P = tab.counts()[0]
+
+    def dep_graph_load_modtab(self, tab):
+        self._check(self.lib.mcx_dep_graph_load_modtab(self.h, tab.h), "mcx_dep_graph_load_modtab")
+        rowptr, col = tab.dep_arrays(True)
+        self.V, self.E = len(rowptr) - 1, len(col)
+
     def fleet_roots(self, S, s_off, dev_off, extra_off, extra_ids, safe_name, cap=None):
         """(root_off, root_ids) of mcx_fleet_roots; sizes root_ids itself when cap is None"""
         S, s_off = _as(S, np.uint8), _as(s_off, np.uint32)
@@ -339,3 +372,94 @@ def safe_module_names(names):
     if rc != 0:
         raise McxError(rc, "mcx_safe_module_names")
     return out[: len(names)]
+
+
+class ModTab:
+    """Text tables (modules.alias, modules.dep, /proc/modules) parsed by the library."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.h = self.lib.mcx_modtab_create()
+        if not self.h:
+            raise MemoryError("mcx_modtab_create")
+
+    def close(self):
+        if self.h:
+            self.lib.mcx_modtab_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise McxError(rc, what, self.lib.mcx_modtab_last_error(self.h).decode(errors="replace"))
+
+    def add_alias_text(self, text):
+        b = text.encode() if isinstance(text, str) else text
+        self._check(self.lib.mcx_modtab_add_alias_text(self.h, b, len(b)), "mcx_modtab_add_alias_text")
+
+    def add_dep_text(self, text):
+        b = text.encode() if isinstance(text, str) else text
+        self._check(self.lib.mcx_modtab_add_dep_text(self.h, b, len(b)), "mcx_modtab_add_dep_text")
+
+    def load_dir(self, path):
+        self._check(self.lib.mcx_modtab_load_dir(self.h, path.encode()), "mcx_modtab_load_dir")
+
+    def counts(self):
+        p, v, nb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        self._check(self.lib.mcx_modtab_counts(self.h, ctypes.byref(p), ctypes.byref(v), ctypes.byref(nb)),
+                    "mcx_modtab_counts")
+        return p.value, v.value, nb.value
+
+    def alias_arrays(self):
+        """copies of (arena uint8, a_off uint32[P+1], a_mod uint32[P])"""
+        P, _, nb = self.counts()
+        a, o, m = _vp(), _vp(), _vp()
+        self._check(self.lib.mcx_modtab_alias_arrays(self.h, ctypes.byref(a), ctypes.byref(o), ctypes.byref(m)),
+                    "mcx_modtab_alias_arrays")
+        arena = np.frombuffer(ctypes.string_at(a.value, nb), dtype=np.uint8).copy() if nb else np.zeros(0, np.uint8)
+        a_off = np.frombuffer(ctypes.string_at(o.value, 4 * (P + 1)), dtype=np.uint32).copy()
+        a_mod = np.frombuffer(ctypes.string_at(m.value, 4 * P), dtype=np.uint32).copy() if P else np.zeros(0, np.uint32)
+        return arena, a_off, a_mod
+
+    def dep_arrays(self, direct=True):
+        """copies of (rowptr uint32[V+1], col uint32[E])"""
+        _, V, _ = self.counts()
+        r, c, e = _vp(), _vp(), ctypes.c_uint32()
+        self._check(self.lib.mcx_modtab_dep_arrays(self.h, int(direct), ctypes.byref(r), ctypes.byref(c),
+                                                   ctypes.byref(e)), "mcx_modtab_dep_arrays")
+        rowptr = np.frombuffer(ctypes.string_at(r.value, 4 * (V + 1)), dtype=np.uint32).copy()
+        col = np.frombuffer(ctypes.string_at(c.value, 4 * e.value), dtype=np.uint32).copy() if e.value else \
+            np.zeros(0, np.uint32)
+        return rowptr, col
+
+    def module_name(self, mid):
+        s = self.lib.mcx_modtab_module_name(self.h, int(mid))
+        return s.decode() if s is not None else None
+
+    def module_id(self, name):
+        return self.lib.mcx_modtab_module_id(self.h, name.encode() if isinstance(name, str) else name)
+
+    def module_names(self):
+        _, V, _ = self.counts()
+        return [self.module_name(m) for m in range(V)]
+
+    def mark_loaded(self, proc_modules_text, in_flags=None):
+        """(in_flags uint8[V] with LOADED set, number of names not in the table)"""
+        _, V, _ = self.counts()
+        f = np.zeros(max(V, 1), dtype=np.uint8) if in_flags is None else in_flags
+        b = proc_modules_text.encode() if isinstance(proc_modules_text, str) else proc_modules_text
+        unknown = ctypes.c_uint32()
+        self._check(self.lib.mcx_modtab_mark_loaded(self.h, b, len(b), _ptr(f), ctypes.byref(unknown)),
+                    "mcx_modtab_mark_loaded")
+        return f[:V], unknown.value

@@ -228,3 +228,58 @@ def test_k2_full_size(gpu_ctx, oracle_mod):
     src = np.repeat(np.arange(V, dtype=np.uint32), np.diff(rowptr))
     viol = bits[col] & loaded[src] & ~bits[src]
     assert not viol.any()
+
+
+# ---- text tables in front of the kernels -------------------------------------------
+
+def test_text_tables_resolve_like_kmod(gpu_ctx):
+    """modules.alias text -> table -> match: the module kmod resolves for each query of
+    the committed modprobe fixture, and all of its matches in file order"""
+    from montecarlo_amd import ModTab, TABLE_NORMALIZE_DASH
+
+    fx = load("kmod_resolve.json")
+    text = "# generated\n" + "".join(f"alias {p} {m}\n" for p, m in fx["aliases"])
+    with ModTab() as t:
+        t.add_alias_text(text)
+        gpu_ctx.alias_table_load_modtab(t, TABLE_NORMALIZE_DASH)
+        _, _, a_mod = t.alias_arrays()
+        S, s_off = pack_strings([q["query"].encode() for q in fx["queries"]])
+        first, count = gpu_ctx.alias_match(S, s_off)
+        for i, q in enumerate(fx["queries"]):
+            assert count[i] == len(q["modules"]), q
+            if q["modules"]:
+                assert t.module_name(a_mod[first[i]]) == q["modules"][0].replace("-", "_"), q
+            else:
+                assert first[i] == NO_MATCH
+
+
+def test_text_tables_dashboard_flow(gpu_ctx, oracle_mod):
+    """modules.dep + /proc/modules text -> direct edges -> dep flags: the modules the
+    dashboard would list for that host (loaded, safe, nobody holds them)"""
+    from montecarlo_amd import ModTab, safe_module_names
+
+    dep = ("kernel/a/e1000e.ko.zst: kernel/b/ptp.ko.zst kernel/c/pps_core.ko.zst\n"
+           "kernel/b/ptp.ko.zst: kernel/c/pps_core.ko.zst\n"
+           "kernel/c/pps_core.ko.zst:\n"
+           "kernel/d/r8152.ko: kernel/d/mii.ko\n"
+           "kernel/d/mii.ko:\n"
+           "kernel/e/snd-hda-intel.ko: kernel/e/snd-hda-core.ko\n"
+           "kernel/e/snd-hda-core.ko:\n"
+           "kernel/f/igb.ko:\n")
+    proc = ("e1000e 1 0 - Live 0x0\nptp 1 1 e1000e, Live 0x0\npps_core 1 1 ptp, Live 0x0\n"
+            "snd_hda_intel 1 0 - Live 0x0\nsnd_hda_core 1 1 snd_hda_intel, Live 0x0\nigb 1 0 - Live 0x0\n")
+    with ModTab() as t:
+        t.add_dep_text(dep)
+        names = t.module_names()
+        flags, unknown = t.mark_loaded(proc)
+        assert unknown == 0
+        flags = flags | (safe_module_names(names) << 2)
+        gpu_ctx.dep_graph_load_modtab(t)
+        out, ref = gpu_ctx.dep_flags(flags)
+        rowptr, col = t.dep_arrays(True)
+        o_out, o_ref = oracle_mod.dep_flags(rowptr, col, flags)
+        assert np.array_equal(out, o_out) and np.array_equal(ref, o_ref)
+        roots = sorted(names[i] for i in np.nonzero(out & 4)[0])
+        assert roots == ["e1000e", "igb"]          # snd_* fails the name filter, the others are held
+        held = sorted(names[i] for i in np.nonzero(out & 1)[0])
+        assert held == ["pps_core", "ptp", "snd_hda_core"]
