@@ -201,7 +201,7 @@ int mcx_safe_table_sizes(uint32_t *n_core, uint32_t *n_prefix);
  * entries) is too small the call returns MCX_E_TOO_LARGE with *total_out and
  * root_off filled in, so the caller can allocate and call again.  Module ids
  * >= V in a_mod or extra_ids are ignored.  A graph with a dependency cycle is
- * refused (MCX_E_BAD_ARG), so is a table loaded with MCX_TABLE_NORMALIZE_DASH.
+ * refused (MCX_E_BAD_ARG).
  * Device memory: 8 * V * ceil(H/32) bytes of scratch; a fleet that does not fit
  * is split by the caller into groups of hosts (hosts are independent).
  * Every listed module is idle in the sense of mc_driver_is_in_use

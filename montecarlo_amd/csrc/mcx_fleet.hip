@@ -391,10 +391,6 @@ int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
         return MCX_E_BAD_ARG;
     if (!ctx->table_loaded || !ctx->graph_loaded)
         return MCX_E_NOT_LOADED;
-    if (ctx->norm_dash) {
-        ctx->err = "a table loaded with MCX_TABLE_NORMALIZE_DASH cannot be used by the fleet pipeline";
-        return MCX_E_BAD_ARG;
-    }
     if (dev_off[0] != 0 || dev_off[H] != N || extra_off[0] != 0) {
         ctx->err = "dev_off must run from 0 to N and extra_off from 0";
         return MCX_E_BAD_ARG;

@@ -60,6 +60,10 @@ struct mcx_ctx {
     uint32_t *d_lvl_order = nullptr;
     std::vector<uint32_t> lvl_ptr;
 
+    /* staging of the host-buffer alias match, grown on demand */
+    void *d_io = nullptr;
+    size_t io_bytes = 0;
+
     /* scratch of the fleet pipeline, grown on demand, freed with the context */
     void *d_fleet = nullptr;
     size_t fleet_bytes = 0;

@@ -38,6 +38,7 @@ struct k1_table_t {
     uint32_t slot_mask;
     uint32_t nlens;
     uint32_t nlens_magic;   /* ceil(2^32 / nlens): x / nlens = mulhi(x, magic) for x < 2^16 */
+    uint32_t norm_dash;     /* strings get kmod's '-' -> '_' rule before they are matched */
 };
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
@@ -60,11 +61,33 @@ struct LdsStr {
 };
 
 /* a string read in place (tiles too long for the staging buffer): bounded
- * byte reads, bytes past the end read as 0 */
+ * byte reads, bytes past the end read as 0.  With `norm` a '-' outside a
+ * bracket pair reads as '_': the nearest '[' or ']' in front of it says which
+ * (this path is rare and favours being right over being fast). */
+__device__ __attribute__((noinline)) uint32_t k1_dash_in_place(const uint8_t *p, uint32_t q)
+{
+    for (uint32_t r = q; r-- > 0u;) {
+        if (p[r] == '[')
+            return '-';
+        if (p[r] == ']')
+            break;
+    }
+    return '_';
+}
+
 struct GlobalStr {
     const uint8_t *p;
     uint32_t len;
-    __device__ __forceinline__ uint32_t byte(uint32_t q) const { return q < len ? (uint32_t)p[q] : 0u; }
+    uint32_t norm;
+    __device__ __forceinline__ uint32_t byte(uint32_t q) const
+    {
+        if (q >= len)
+            return 0u;
+        const uint32_t c = p[q];
+        if (!norm || c != '-')
+            return c;
+        return k1_dash_in_place(p, q); /* out of line: rare, and kept off the common path's registers */
+    }
     __device__ __forceinline__ uint32_t word(uint32_t q) const
     {
         return byte(q) | (byte(q + 1) << 8) | (byte(q + 2) << 16) | (byte(q + 3) << 24);
@@ -124,8 +147,83 @@ struct __attribute__((aligned(4))) k1_sig4_t {
  *     Matches go to per-string min / count cells in LDS, stored at the end.
  * The block owns its strings: no global atomics, no pre-initialised output.
  */
+/*
+ * kmod's rule for the queried alias: '-' becomes '_' outside [...]; a ']'
+ * without its '[' or a '[' that is never closed makes the query unresolvable
+ * (refused[slot] = 1).  The staged bytes of a tile are rewritten in LDS, one
+ * wave per string, 64 bytes a step: the bracket pairs of a step come from two
+ * ballots and a scalar walk over them (none at all in a modalias the kernel
+ * wrote).  A tile read in place (in_place != nullptr) is only checked; its
+ * dashes are translated when they are read.  Out of line, so that its registers
+ * stay out of the matching path.  Called by all threads of the block; the
+ * caller synchronises afterwards.
+ */
+__device__ __attribute__((noinline)) void k1_normalize_tile(uint32_t *str_w, const uint32_t *str_at,
+                                                            const uint32_t *str_len, uint32_t *refused,
+                                                            uint32_t nstr, const uint8_t *in_place)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (in_place) {
+        for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
+            const uint8_t *p = in_place + str_at[i];
+            const uint32_t len = str_len[i];
+            bool inside = false, bad = false;
+            for (uint32_t q = 0; q < len && !bad; ++q) {
+                if (inside)
+                    inside = p[q] != ']';
+                else if (p[q] == ']')
+                    bad = true;
+                else
+                    inside = p[q] == '[';
+            }
+            refused[i] = (bad || inside) ? 1u : 0u;
+        }
+        return;
+    }
+    for (uint32_t slot = wave; slot < nstr; slot += K1_WAVES) {
+        const uint32_t len = str_len[slot], at = str_at[slot];
+        bool inside = false, bad = false;
+        for (uint32_t base = 0; base < len && !bad; base += 64u) {
+            const uint32_t q = base + lane, a = at + q;
+            const uint32_t c = q < len ? (str_w[a >> 2] >> ((a & 3u) * 8u)) & 0xFFu : 0u;
+            const unsigned long long O = __ballot(c == '['), C = __ballot(c == ']');
+            unsigned long long in_mask = 0;
+            uint32_t pos = 0;
+            while (pos < 64u) {
+                const unsigned long long from = ~0ull << pos;
+                if (inside) {
+                    const unsigned long long rest = C & from;
+                    if (!rest) {
+                        in_mask |= from;
+                        break;
+                    }
+                    const uint32_t cp = (uint32_t)__builtin_ctzll(rest);
+                    in_mask |= from & (cp == 63u ? ~0ull : ((1ull << (cp + 1u)) - 1ull));
+                    pos = cp + 1u;
+                    inside = false;
+                } else {
+                    const unsigned long long ev = (O | C) & from;
+                    if (!ev)
+                        break;
+                    const uint32_t ep = (uint32_t)__builtin_ctzll(ev);
+                    if ((C >> ep) & 1ull) {
+                        bad = true;
+                        break;
+                    }
+                    inside = true;
+                    pos = ep + 1u;
+                }
+            }
+            if (!bad && q < len && c == '-' && !((in_mask >> lane) & 1ull))
+                atomicXor(&str_w[a >> 2], (uint32_t)('-' ^ '_') << ((a & 3u) * 8u));
+        }
+        if (lane == 0)
+            refused[slot] = (bad || inside) ? 1u : 0u;
+    }
+}
+
 template <bool BULK>
-__global__ void __launch_bounds__(K1_THREADS, 5)
+__global__ void __launch_bounds__(K1_THREADS, 4)
 k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
                  uint32_t str_cap, uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
                  uint32_t *__restrict__ count
@@ -159,7 +257,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     constexpr uint32_t GROUP = BULK ? 64u : K1_GROUP; /* survivors one wave takes per pass */
     __shared__ uint32_t bloom[K1_MAX_SPB][MCX_BLOOM_WORDS];
     __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
-    __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB];
+    __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB], refused[K1_MAX_SPB];
     __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
     __shared__ uint32_t nhits, nunits_sh, ring_cum[2];
     const uint32_t max_hits = spb * T.nlens;
@@ -193,6 +291,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         str_len[i] = s_off[t0 + i + 1] - so;
         res_first[i] = MCX_NO_MATCH;
         res_count[i] = 0;
+        refused[i] = 0;
     }
     for (uint32_t w = tid; w < nstr * MCX_BLOOM_WORDS; w += K1_THREADS) {
         /* strings read in place get a full set: their patterns are not screened */
@@ -227,6 +326,10 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         }
     }
     __syncthreads();
+    if (T.norm_dash) {
+        k1_normalize_tile(str_w, str_at, str_len, refused, nstr, use_lds ? nullptr : S + gbase);
+        __syncthreads();
+    }
     K1_STAMP(1);
 
     /* ---- gram sets: one wave per string, one lane per start position ------- */
@@ -262,7 +365,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
                 kw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
         } else {
-            GlobalStr str{S + gbase + str_at[slot], len};
+            GlobalStr str{S + gbase + str_at[slot], len, T.norm_dash};
 #pragma unroll
             for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
                 kw[k] = (4u * k < L) ? str.word(4u * k) : 0u;
@@ -363,7 +466,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         const FlatProg fp{prog};
         if (use_lds)
             return mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets);
-        return mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len}, len, T.sets);
+        return mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len, T.norm_dash}, len, T.sets);
     };
     uint32_t *my_stage = stage[BULK ? 0u : wave];
     /* many strings per block: a lane per survivor, its slot read in place; the
@@ -592,8 +695,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     __syncthreads();
     K1_STAMP(5);
     for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
-        first_idx[t0 + i] = res_first[i];
-        count[t0 + i] = res_count[i];
+        first_idx[t0 + i] = refused[i] ? MCX_NO_MATCH : res_first[i];
+        count[t0 + i] = refused[i] ? 0u : res_count[i];
     }
     K1_STAMP(6);
 #ifdef MCX_K1_STAMPS
@@ -724,6 +827,7 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     T.slot_mask = ctx->slot_mask;
     T.nlens = ctx->nlens;
     T.nlens_magic = ctx->nlens ? (uint32_t)((((uint64_t)1 << 32) + ctx->nlens - 1u) / ctx->nlens) : 0u;
+    T.norm_dash = ctx->norm_dash ? 1u : 0u;
     /* staging buffer: 256 bytes per string of the tile, between 1 KiB and 8 KiB;
      * a tile that needs more is read in place */
     uint32_t str_cap = spb * 256u;
@@ -762,10 +866,6 @@ int mcx_alias_match_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
         return MCX_E_BAD_ARG;
     if (!ctx->table_loaded)
         return MCX_E_NOT_LOADED;
-    if (ctx->norm_dash) {
-        ctx->err = "MCX_TABLE_NORMALIZE_DASH needs the host-buffer entry point";
-        return MCX_E_BAD_ARG;
-    }
     if (mcx_set_device(ctx))
         return MCX_E_HIP;
     return launch_alias_match(ctx, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N,
@@ -790,76 +890,37 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
             ctx->err = "s_off not monotonic";
             return MCX_E_BAD_ARG;
         }
-    std::vector<char> norm;
-    const char *src = S;
-    if (ctx->norm_dash) {
-        /* kmod applies the '-' -> '_' rule to the queried alias as well; a
-         * query it refuses (unmatched bracket) resolves to nothing, so the
-         * results of such strings are cleared after the match. */
-        norm.assign(S, S + s_off[N]);
-        src = norm.data();
-    }
-    std::vector<uint8_t> refused;
-    if (ctx->norm_dash) {
-        refused.assign(N, 0);
-        for (uint32_t i = 0; i < N; ++i) {
-            char *p = norm.data();
-            for (uint32_t k = s_off[i]; k < s_off[i + 1]; ++k) {
-                if (p[k] == '-') {
-                    p[k] = '_';
-                } else if (p[k] == ']') {
-                    refused[i] = 1;
-                    break;
-                } else if (p[k] == '[') {
-                    while (k < s_off[i + 1] && p[k] != ']')
-                        ++k;
-                    if (k >= s_off[i + 1]) {
-                        refused[i] = 1;
-                        break;
-                    }
-                }
-            }
+    /* staging area kept by the context and grown on demand: one allocation
+     * holds the strings, their offsets and both result arrays */
+    const size_t sbytes = s_off[N];
+    const size_t o_off = (sbytes + 255) & ~(size_t)255, o_first = o_off + ((4 * ((size_t)N + 1) + 255) & ~(size_t)255);
+    const size_t o_count = o_first + ((4 * (size_t)N + 255) & ~(size_t)255);
+    const size_t need = o_count + 4 * (size_t)N;
+    if (ctx->io_bytes < need) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_io);
+        ctx->d_io = nullptr;
+        ctx->io_bytes = 0;
+        const size_t want = need + need / 2;
+        if (hipMalloc(&ctx->d_io, want) != hipSuccess) {
+            ctx->err = "hipMalloc of " + std::to_string(want) + " bytes of staging failed";
+            return MCX_E_NOMEM;
         }
+        ctx->io_bytes = want;
     }
-    uint8_t *d_S = nullptr;
-    uint32_t *d_off = nullptr, *d_first = nullptr, *d_count = nullptr;
-    int rc = MCX_OK;
-    hipError_t e;
-    size_t sbytes = s_off[N];
-    if ((e = hipMalloc((void **)&d_S, sbytes ? sbytes : 1)) != hipSuccess ||
-        (e = hipMalloc((void **)&d_off, 4 * ((size_t)N + 1))) != hipSuccess ||
-        (e = hipMalloc((void **)&d_first, 4 * (size_t)N)) != hipSuccess ||
-        (e = hipMalloc((void **)&d_count, 4 * (size_t)N)) != hipSuccess) {
-        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
-        rc = MCX_E_NOMEM;
-    }
-    if (rc == MCX_OK && sbytes &&
-        (e = hipMemcpyAsync(d_S, src, sbytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-        rc = MCX_E_HIP;
-    if (rc == MCX_OK &&
-        (e = hipMemcpyAsync(d_off, s_off, 4 * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-        rc = MCX_E_HIP;
-    if (rc == MCX_OK)
-        rc = launch_alias_match(ctx, d_S, d_off, N, d_first, d_count);
-    if (rc == MCX_OK &&
-        ((e = hipMemcpyAsync(first_idx, d_first, 4 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
-         (e = hipMemcpyAsync(count, d_count, 4 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
-         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess)) {
-        ctx->err = std::string("copy back: ") + hipGetErrorString(e);
-        rc = MCX_E_HIP;
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_S);
-    (void)hipFree(d_off);
-    (void)hipFree(d_first);
-    (void)hipFree(d_count);
-    if (rc == MCX_OK && ctx->norm_dash)
-        for (uint32_t i = 0; i < N; ++i)
-            if (refused[i]) {
-                first_idx[i] = MCX_NO_MATCH;
-                count[i] = 0;
-            }
-    return rc;
+    uint8_t *base = (uint8_t *)ctx->d_io;
+    uint32_t *d_off = (uint32_t *)(base + o_off), *d_first = (uint32_t *)(base + o_first);
+    uint32_t *d_count = (uint32_t *)(base + o_count);
+    if (sbytes)
+        HIPCHK(ctx, hipMemcpyAsync(base, S, sbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_off, s_off, 4 * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_alias_match(ctx, base, d_off, N, d_first, d_count);
+    if (rc != MCX_OK)
+        return rc;
+    HIPCHK(ctx, hipMemcpyAsync(first_idx, d_first, 4 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(count, d_count, 4 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MCX_OK;
 }
 
 int mcx_alias_driver_mod_dev(mcx_ctx *ctx, const void *d_first_idx, uint32_t N, void *d_driver_mod)

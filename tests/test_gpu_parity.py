@@ -230,6 +230,36 @@ def test_k2_full_size(gpu_ctx, oracle_mod):
     assert not viol.any()
 
 
+def test_k1_normalize_dash_on_device(gpu_ctx, oracle_mod):
+    """kmod's '-' -> '_' rule applied to the queried strings by the kernel: dashes in
+    and outside brackets, unmatched brackets (unresolvable), bracket pairs that cross
+    the 64-byte steps of the scan, strings on both sides of the 64-byte matcher switch;
+    through the host-buffer and the device-buffer entry points"""
+    rng = np.random.default_rng(123)
+    pats = [b"a-b*", b"a_b*", b"*-*", b"*_*", b"x[a-c]y*", b"*[[]*", b"ab", b"*", b"a?b*z", b"*a-b",
+            b"foo-bar:v*", b"*q_[_-]*", b"[x-]*"]
+    alpha = list(b"ab-_xq") + [ord("["), ord("]")]
+    strs = [b"", b"a-b", b"a_b", b"-", b"a-bz", b"[a-b]", b"a[-]b-c", b"a]b", b"a[b", b"x[a-c]y", b"foo-bar:v12",
+            b"a-b" + b"x" * 62 + b"[--]" + b"-" * 5, b"x" * 63 + b"[" + b"-" * 10 + b"]-", b"-" * 200,
+            b"[" + b"a" * 130 + b"]-z", b"q" * 64 + b"]"]
+    for _ in range(300):
+        strs.append(bytes(rng.choice(alpha) for _ in range(int(rng.integers(0, 150)))))
+    A, a_off = pack_strings(pats)
+    S, s_off = pack_strings(strs)
+    a_mod = np.arange(len(pats), dtype=np.uint32)
+    first, count = check_k1(gpu_ctx, oracle_mod, A, a_off, a_mod, S, s_off, flags=1)
+    assert (first == NO_MATCH).any() and (count > 3).any()
+    # same through device buffers
+    N = len(strs)
+    dS, dO = gpu_ctx.to_device(S), gpu_ctx.to_device(s_off)
+    dF, dC = gpu_ctx.alloc(4 * N), gpu_ctx.alloc(4 * N)
+    gpu_ctx.alias_match_dev(dS.ptr, dO.ptr, N, dF.ptr, dC.ptr)
+    gpu_ctx.sync()
+    assert np.array_equal(dF.download(np.uint32, N), first) and np.array_equal(dC.download(np.uint32, N), count)
+    for b in (dS, dO, dF, dC):
+        b.free()
+
+
 # ---- text tables in front of the kernels -------------------------------------------
 
 def test_text_tables_resolve_like_kmod(gpu_ctx):
