@@ -12,6 +12,7 @@ Prints ONE JSON line (rank 0).  Beside the headline value it carries
   roofline      algorithmic bytes of one K1 launch / measured device time
   cpu_baseline  the CPU oracle (glibc fnmatch loop) timed on the host cores
   k2            dependency flags + closure on configs[2] (1M modules, ~10M edges)
+  fleet         the fused inventory pipeline on configs[4] (100000 hosts, ~10M devices)
 """
 import argparse
 import json
@@ -42,6 +43,9 @@ def parse():
                     help="with --gpus N>1: every rank its own strings against the whole table (default, no "
                          "collective), or every rank a slice of the table against all strings + MIN/SUM all-reduce")
     ap.add_argument("--no-k2", action="store_true")
+    ap.add_argument("--no-fleet", action="store_true")
+    ap.add_argument("--fleet-hosts", type=int, default=100_000)
+    ap.add_argument("--fleet-devices", type=int, default=100, help="mean devices per host")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -94,7 +98,7 @@ def cpu_baseline_k1(A, a_off, S, s_off, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or passes >= 1000:
             break
-    return {
+    res = {
         "value": passes * N * P / el,
         "unit": "pairs/s",
         "cores": cores,
@@ -102,6 +106,38 @@ def cpu_baseline_k1(A, a_off, S, s_off, budget_s):
         "sample": f"{passes} whole passes of the same {N}x{P} workload, glibc fnmatch(p,s,0) double loop, "
                   f"{cores} threads over strings, {el:.1f} s",
     }
+    # beside the naive loop: the same index, screen and matchers the GPU uses, on the host cores
+    # (the product's pattern compiler and matcher routines built for the CPU by the test twin)
+    s_off32 = np.ascontiguousarray(s_off, dtype=np.uint32)
+    S8 = np.ascontiguousarray(S if len(S) else np.zeros(1, np.uint8), dtype=np.uint8)
+    table = oracle.TwinTable(A, a_off)
+    first = np.zeros(N, dtype=np.uint32)
+    count = np.zeros(N, dtype=np.uint32)
+
+    def work_indexed(k):
+        if bounds[k + 1] > bounds[k]:
+            table.match(S8, s_off32, first, count, bounds[k], bounds[k + 1])
+
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        th = [threading.Thread(target=work_indexed, args=(k,)) for k in range(cores)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s / 4 or passes >= 20000:
+            break
+    table.close()
+    res["indexed"] = {
+        "value": passes * N * P / el,
+        "unit": "pairs/s",
+        "cores": cores,
+        "sample": f"{passes} passes of the same workload through the prefix index + gram screen + segment "
+                  f"matcher on the CPU (table compiled once, not timed), {el:.1f} s",
+    }
+    return res
 
 
 def main():
@@ -223,6 +259,8 @@ def main():
 
     if rank == 0 and not args.no_k2:
         out["k2"] = bench_k2(ctx, synth, args)
+    if rank == 0 and not args.no_fleet:
+        out["fleet"] = bench_fleet(ctx, synth, args)
     if rank == 0 and not args.no_cpu:
         import oracle
 
@@ -292,6 +330,59 @@ def bench_k2(ctx, synth, args):
     for b in (d_in, d_seed, d_out, d_ref, d_clo):
         b.free()
     return res
+
+
+def bench_fleet(ctx, synth, args):
+    """configs[4]: alias match -> used drivers -> loaded set -> holders -> root filter for a
+    whole fleet, inputs resident in HBM."""
+    from montecarlo_amd import safe_module_names
+
+    H, P, seed = args.fleet_hosts, args.patterns, 5
+    A, a_off, a_mod = synth.alias_table(seed, P)
+    V = synth.alias_modules(P)
+    rowptr, col = synth.dep_graph(seed + 1, V, args.graph_degree)
+    dev_cnt, extra_off, extra_ids = synth.fleet_hosts(seed + 2, V, H, args.fleet_devices, 8)
+    dev_off = np.zeros(H + 1, dtype=np.uint32)
+    dev_off[1:] = np.cumsum(dev_cnt)
+    N = int(dev_off[H])
+    S, s_off = synth.modalias_strings(seed + 3, P, N)
+    safe = safe_module_names(synth.module_names(seed + 4, V))
+    ctx.alias_table_load(A, a_off, a_mod)
+    ctx.dep_graph_load(rowptr, col)
+    bufs = [ctx.to_device(x) for x in (S, s_off, dev_off, extra_off, extra_ids, safe)]
+    d_S, d_soff, d_dev, d_xoff, d_xid, d_safe = bufs
+    d_roff = ctx.alloc(4 * (H + 1))
+    X = len(extra_ids)
+    total = ctx.fleet_roots_dev(d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_xoff.ptr, d_xid.ptr, X, d_safe.ptr,
+                                d_roff.ptr, None, 0, size_only=True)
+    d_rid = ctx.alloc(4 * max(total, 1))
+    reps = 3
+    for _ in range(reps + 1):  # first pass untimed
+        if _ == 1:
+            ctx.sync()
+            t0 = time.perf_counter()
+        ctx.fleet_roots_dev(d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_xoff.ptr, d_xid.ptr, X, d_safe.ptr,
+                            d_roff.ptr, d_rid.ptr, total)
+    ctx.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    d_f, d_c = ctx.alloc(4 * N), ctx.alloc(4 * N)
+    ctx.alias_match_dev(d_S.ptr, d_soff.ptr, N, d_f.ptr, d_c.ptr)
+    ctx.timer_begin()
+    ctx.alias_match_dev(d_S.ptr, d_soff.ptr, N, d_f.ptr, d_c.ptr)
+    k1_ms = ctx.timer_end()
+    for b in bufs + [d_roff, d_rid, d_f, d_c]:
+        b.free()
+    return {
+        "workload": f"configs[4]: {H} hosts, {N} devices, {P} alias patterns, {V} modules, {len(col)} edges, "
+                    f"{X} extra loaded modules, seed {seed}",
+        "ms_per_pass": ms,
+        "devices_per_s": N / (ms / 1e3),
+        "hosts_per_s": H / (ms / 1e3),
+        "listed_modules": total,
+        "alias_match_ms": k1_ms,
+        "pairs_per_s": N * P / (k1_ms / 1e3),
+        "input_bytes": int(len(S) + 4 * (N + 1) + 4 * (H + 1) * 2 + 4 * X + V),
+    }
 
 
 if __name__ == "__main__":

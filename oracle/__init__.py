@@ -62,6 +62,12 @@ def twin():
         lib.twin_fnmatch.argtypes = [ctypes.c_char_p, u32, ctypes.c_char_p, u32]
         lib.twin_alias_match.restype = ctypes.c_int
         lib.twin_alias_match.argtypes = [_vp, _vp, u32, _vp, _vp, u32, u32, ctypes.c_int, _vp, _vp]
+        lib.twin_table_create.restype = _vp
+        lib.twin_table_create.argtypes = [_vp, _vp, u32, ctypes.c_int]
+        lib.twin_table_destroy.restype = None
+        lib.twin_table_destroy.argtypes = [_vp]
+        lib.twin_table_match.restype = ctypes.c_int
+        lib.twin_table_match.argtypes = [_vp, _vp, _vp, u32, u32, _vp, _vp]
         _TWIN = lib
     return _TWIN
 
@@ -134,3 +140,22 @@ def fleet_roots(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe_nam
     ids = np.zeros(max(total, 1), dtype=np.uint32)
     oracle().orc_fleet_roots(*args, _p(ids))
     return root_off, ids[:total]
+
+
+class TwinTable:
+    """the CPU twin's compiled table, kept between calls (indexed CPU baseline)"""
+
+    def __init__(self, arena, a_off, normalize_dash=False):
+        a_off = np.ascontiguousarray(a_off, dtype=np.uint32)
+        self.h = twin().twin_table_create(_p(_c(arena, np.uint8)), _p(a_off), len(a_off) - 1, int(normalize_dash))
+        if not self.h:
+            raise RuntimeError("twin_table_create failed")
+
+    def match(self, S, s_off, first, count, i0, i1):
+        """fills first[i0:i1], count[i0:i1] (uint32 arrays of N entries)"""
+        twin().twin_table_match(self.h, _p(S), _p(s_off), i0, i1, _p(first), _p(count))
+
+    def close(self):
+        if self.h:
+            twin().twin_table_destroy(self.h)
+            self.h = None

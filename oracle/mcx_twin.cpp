@@ -112,24 +112,44 @@ int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t 
     return r;
 }
 
-/* Same contract as orc_alias_match; returns 0 or a negative MCX_E_* code.
- * Candidates come from the literal-prefix index, probed the way the device
- * probes it, so the index is covered too. */
-int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const char *S,
-                     const uint32_t *s_off, uint32_t i0, uint32_t i1, int normalize_dash,
+/* A compiled table kept between calls, so that the indexed CPU path can be
+ * timed without the pattern compiler (the CPU baseline that is not the naive
+ * double loop). */
+struct twin_table {
+    mcx_compiled_table t;
+    bool normalize_dash;
+};
+
+void *twin_table_create(const char *arena, const uint32_t *a_off, uint32_t P, int normalize_dash)
+{
+    twin_table *tt = new twin_table();
+    std::string err;
+    tt->normalize_dash = normalize_dash != 0;
+    if (mcx_compile_table(arena, a_off, P, tt->normalize_dash, tt->t, err) != 0) {
+        delete tt;
+        return nullptr;
+    }
+    return tt;
+}
+
+void twin_table_destroy(void *h)
+{
+    delete (twin_table *)h;
+}
+
+/* strings i0..i1 against a kept table; candidates come from the literal-prefix
+ * index, probed the way the device probes it, so the index is covered too */
+int twin_table_match(void *h, const char *S, const uint32_t *s_off, uint32_t i0, uint32_t i1,
                      uint32_t *first_idx, uint32_t *count)
 {
-    mcx_compiled_table t;
-    std::string err;
-    int rc = mcx_compile_table(arena, a_off, P, normalize_dash != 0, t, err);
-    if (rc != 0)
-        return rc;
+    const twin_table *tt = (const twin_table *)h;
+    const mcx_compiled_table &t = tt->t;
     const uint32_t *sets = t.sets.empty() ? nullptr : t.sets.data();
     const size_t mask = t.slots.size() - 1;
     for (uint32_t i = i0; i < i1; ++i) {
         std::string str(S + s_off[i], S + s_off[i + 1]);
         bool bad = false;
-        if (normalize_dash)
+        if (tt->normalize_dash)
             normalize(str, &bad);
         uint32_t first = MCX_NO_MATCH, cnt = 0;
         if (!bad) {
@@ -173,6 +193,20 @@ int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const
         count[i] = cnt;
     }
     return 0;
+}
+
+/* Same contract as orc_alias_match; returns 0 or a negative MCX_E_* code. */
+int twin_alias_match(const char *arena, const uint32_t *a_off, uint32_t P, const char *S,
+                     const uint32_t *s_off, uint32_t i0, uint32_t i1, int normalize_dash,
+                     uint32_t *first_idx, uint32_t *count)
+{
+    twin_table tt;
+    std::string err;
+    tt.normalize_dash = normalize_dash != 0;
+    int rc = mcx_compile_table(arena, a_off, P, tt.normalize_dash, tt.t, err);
+    if (rc != 0)
+        return rc;
+    return twin_table_match(&tt, S, s_off, i0, i1, first_idx, count);
 }
 
 } /* extern "C" */
