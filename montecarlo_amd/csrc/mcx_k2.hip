@@ -28,36 +28,56 @@
 
 /* ------------------------------------------------------------------------- */
 /* K2a: one block = one row block of the reverse CSR.                         */
-/* Every edge (holder u of row v) is read once, coalesced; its row is found   */
-/* by bisection in the block's slice of rrowptr held in LDS; loaded holders   */
-/* are counted per row in LDS; the block then writes the flags and counts of  */
-/* its own rows.  No global atomics, no zero-filled scratch.                   */
+/* Every edge (holder u of row v) is read once, coalesced, and answers "is u  */
+/* loaded" from a packed bitmap; the answers of 64 edges are one ballot, kept */
+/* in LDS as one bit per edge; a row's loaded holders are then the set bits   */
+/* of its edge range.  The block writes the flags and counts of its own rows. */
+/* No atomics, no search for the row of an edge, no zero-filled scratch.      */
+/* What bounds it is the per-edge gather: 10^7 random 4-byte reads go through */
+/* the vector cache at about one lane address per cycle and CU.               */
 /* ------------------------------------------------------------------------- */
+
+/* LOADED bits of in_flags packed 32 modules to a word: the per-edge gather of
+ * K2a then reads a 125 KB array (V = 10^6) that stays in cache, not V bytes */
+__global__ void __launch_bounds__(K2_THREADS)
+k2_loaded_bitmap(const uint8_t *__restrict__ in_flags, uint32_t V, uint32_t *__restrict__ bm)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = v < V && (in_flags[v] & MCX_F_LOADED);
+    const unsigned long long m = __ballot(on);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane == 0u && v < V)
+        bm[v >> 5] = (uint32_t)m;
+    if (lane == 32u && v < V)
+        bm[v >> 5] = (uint32_t)(m >> 32);
+}
 
 __global__ void __launch_bounds__(K2_THREADS)
 k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ rcol,
               const uint32_t *__restrict__ part, const uint8_t *__restrict__ in_flags,
-              uint8_t *__restrict__ out_flags, uint32_t *__restrict__ refcnt)
+              const uint32_t *__restrict__ loaded_bm, uint8_t *__restrict__ out_flags,
+              uint32_t *__restrict__ refcnt)
 {
     __shared__ uint32_t rp[K2_ROWS + 1];
     __shared__ uint32_t cnt[K2_ROWS];
     __shared__ uint32_t wsum[K2_THREADS / 64];
+    __shared__ uint32_t ebits[K2_EDGES / 32u + 8u];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t r0 = part[blockIdx.x], r1 = part[blockIdx.x + 1];
     const uint32_t R = r1 - r0;
     for (uint32_t i = tid; i <= R; i += K2_THREADS)
         rp[i] = rrowptr[r0 + i];
-    if (tid < K2_ROWS)
-        cnt[tid] = 0;
     __syncthreads();
     const uint32_t e0 = rp[0], e1 = rp[R];
 
     if (R == 1u) {
         /* one (possibly very long) row: count in registers, reduce once */
         uint32_t mine = 0;
-        for (uint32_t e = e0 + tid; e < e1; e += K2_THREADS)
-            mine += in_flags[rcol[e]] & MCX_F_LOADED;
+        for (uint32_t e = e0 + tid; e < e1; e += K2_THREADS) {
+            const uint32_t u = rcol[e];
+            mine += (loaded_bm[u >> 5] >> (u & 31u)) & 1u;
+        }
 #pragma unroll
         for (uint32_t d = 32; d >= 1; d >>= 1)
             mine += __shfl_down(mine, d, 64);
@@ -67,25 +87,42 @@ k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__
         if (tid == 0)
             cnt[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     } else {
-        for (uint32_t e = e0 + tid; e < e1; e += K2_THREADS) {
-            const uint32_t u = rcol[e];
-            if (!(in_flags[u] & MCX_F_LOADED))
-                continue;
-            uint32_t lo = 0, hi = R; /* largest i with rp[i] <= e */
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (rp[mid] <= e)
-                    lo = mid;
-                else
-                    hi = mid;
+        /* edge-parallel and coalesced: "is the holder of edge e loaded", 64
+         * edges per wave step, kept as one bit per edge in LDS ... */
+        const uint32_t ne = e1 - e0, lane = tid & 63u;
+        for (uint32_t base = tid - lane; base < ne; base += K2_THREADS) {
+            uint32_t bit = 0;
+            if (base + lane < ne) {
+                const uint32_t u = rcol[e0 + base + lane];
+                bit = (loaded_bm[u >> 5] >> (u & 31u)) & 1u;
             }
-            atomicAdd(&cnt[lo], 1u);
+            const unsigned long long m = __ballot(bit != 0u);
+            if (lane == 0u) {
+                ebits[base >> 5] = (uint32_t)m;
+                ebits[(base >> 5) + 1u] = (uint32_t)(m >> 32);
+            }
+        }
+        __syncthreads();
+        /* ... then row-parallel: a row's loaded holders = the set bits of its
+         * edge range (no search for the row of an edge, no LDS atomics) */
+        for (uint32_t i = tid; i < R; i += K2_THREADS) {
+            const uint32_t a = rp[i] - e0, b = rp[i + 1u] - e0;
+            uint32_t h = 0;
+            for (uint32_t w = a >> 5; 32u * w < b; ++w) {
+                uint32_t bits = ebits[w];
+                if (32u * w < a)
+                    bits &= 0xFFFFFFFFu << (a & 31u);
+                if (32u * w + 32u > b)
+                    bits &= 0xFFFFFFFFu >> ((32u - (b & 31u)) & 31u);
+                h += (uint32_t)__popc(bits);
+            }
+            cnt[i] = h;
         }
     }
     __syncthreads();
-    if (tid < R) {
-        const uint32_t v = r0 + tid;
-        const uint32_t f = in_flags[v], h = cnt[tid];
+    for (uint32_t i = tid; i < R; i += K2_THREADS) {
+        const uint32_t v = r0 + i;
+        const uint32_t f = in_flags[v], h = cnt[i];
         uint32_t o = 0;
         if (f & MCX_F_LOADED) {
             if (h)
@@ -379,8 +416,12 @@ int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, v
         return MCX_OK;
     if (mcx_set_device(ctx))
         return MCX_E_HIP;
+    /* the bitmap lives in the first frontier queue (V words, idle outside a closure) */
+    uint32_t *bm = ctx->d_queue[0];
+    k2_loaded_bitmap<<<(ctx->V + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
+        (const uint8_t *)d_in_flags, ctx->V, bm);
     k2_flags_rows<<<ctx->n_part, K2_THREADS, 0, ctx->stream>>>(ctx->d_rrowptr, ctx->d_rcol, ctx->d_part,
-                                                              (const uint8_t *)d_in_flags,
+                                                              (const uint8_t *)d_in_flags, bm,
                                                               (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
