@@ -49,6 +49,10 @@ struct mcx_ctx {
     uint32_t *d_rrowptr = nullptr, *d_rcol = nullptr;
     uint32_t *d_part = nullptr;    /* row blocks of the reverse CSR (n_part + 1) */
     uint32_t n_part = 0;
+    /* one slice of rows per CU for the variant of K2a that keeps the whole
+     * LOADED bitmap in LDS (n_cu_part = 0: the graph is too large for it) */
+    uint32_t *d_cu_part = nullptr;
+    uint32_t n_cu_part = 0, cu_rows_max = 0, cu_edges_max = 0;
     uint32_t *d_queue[2] = {nullptr, nullptr}; /* BFS frontiers, V entries each */
     uint32_t *d_bfs = nullptr;     /* per-level frontier sizes + edge counter  */
     uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */

@@ -13,8 +13,10 @@
  *                 most K2_ROWS rows and about K2_EDGES edges each (a row with
  *                 more edges than that is a block of its own)
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "mcx_internal.h"
@@ -123,6 +125,98 @@ k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__
     for (uint32_t i = tid; i < R; i += K2_THREADS) {
         const uint32_t v = r0 + i;
         const uint32_t f = in_flags[v], h = cnt[i];
+        uint32_t o = 0;
+        if (f & MCX_F_LOADED) {
+            if (h)
+                o |= MCX_O_HAS_HOLDERS;
+            if ((f & MCX_F_BOUND) || h)
+                o |= MCX_O_IN_USE;
+            if ((f & MCX_F_SAFE) && !h)
+                o |= MCX_O_ROOT;
+        }
+        out_flags[v] = (uint8_t)o;
+        if (refcnt)
+            refcnt[v] = (f & MCX_F_LOADED) ? h + ((f & MCX_F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
+    }
+}
+
+/*
+ * K2a with the LOADED bitmap in LDS: one block of 1024 threads per CU owns a
+ * contiguous slice of rows with about E / #CU edges.  It copies the whole
+ * bitmap (V/8 bytes) and its slice of rrowptr into LDS, streams its edges once,
+ * coalesced, answering "is the holder loaded" from LDS (the per-edge gather
+ * that bounds the other variant never leaves the CU), keeps the answers as one
+ * bit per edge, and counts every row's set bits.  Used when bitmap + slice fit
+ * the 160 KB of one workgroup.
+ */
+#define K2L_THREADS 1024
+__global__ void __launch_bounds__(K2L_THREADS)
+k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ rcol,
+             const uint32_t *__restrict__ cu_part, const uint8_t *__restrict__ in_flags,
+             const uint32_t *__restrict__ loaded_bm, uint32_t W, uint32_t rows_max,
+             uint8_t *__restrict__ out_flags, uint32_t *__restrict__ refcnt)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t k2_lds[];
+    uint32_t *bm = k2_lds;              /* W words */
+    uint32_t *rp = bm + W;              /* rows_max + 1 */
+    uint32_t *ebits = rp + rows_max + 1u; /* edges_max / 32 + 2 */
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t r0 = cu_part[blockIdx.x], r1 = cu_part[blockIdx.x + 1];
+    const uint32_t R = r1 - r0;
+    for (uint32_t i = tid; i < W; i += K2L_THREADS)
+        bm[i] = loaded_bm[i];
+    for (uint32_t i = tid; i <= R; i += K2L_THREADS)
+        rp[i] = rrowptr[r0 + i];
+    __syncthreads();
+    const uint32_t e0 = rp[0], ne = rp[R] - e0;
+    /* a wave takes 1024 consecutive edges per step, 16 per lane, read with four
+     * 16-byte loads that are all in flight before the first answer is looked
+     * up: enough bytes under way per CU to cover the memory latency.  A lane's
+     * 16 answers are one half-word of the edge-bit array. */
+    uint16_t *ebits16 = (uint16_t *)ebits;
+    const uint32_t wave = tid >> 6;
+    for (uint32_t base = wave * 1024u; base < ne; base += (K2L_THREADS / 64u) * 1024u) {
+        const uint32_t first = base + 16u * lane;
+        uint32_t u[16];
+        if (first + 16u <= ne) {
+            const uint4 *src = (const uint4 *)(rcol + e0 + first); /* 4-byte aligned */
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) {
+                const uint4 v = src[q];
+                u[4u * q] = v.x;
+                u[4u * q + 1u] = v.y;
+                u[4u * q + 2u] = v.z;
+                u[4u * q + 3u] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k)
+                u[k] = first + k < ne ? rcol[e0 + first + k] : 0xFFFFFFFFu;
+        }
+        uint32_t bits = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const bool have = u[k] != 0xFFFFFFFFu;
+            const uint32_t w = bm[have ? u[k] >> 5 : 0u];
+            bits |= (have ? (w >> (u[k] & 31u)) & 1u : 0u) << k;
+        }
+        if (first < ne + 16u)
+            ebits16[first >> 4] = (uint16_t)bits;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < R; i += K2L_THREADS) {
+        const uint32_t a = rp[i] - e0, b = rp[i + 1u] - e0;
+        uint32_t h = 0;
+        for (uint32_t w = a >> 5; 32u * w < b; ++w) {
+            uint32_t bits = ebits[w];
+            if (32u * w < a)
+                bits &= 0xFFFFFFFFu << (a & 31u);
+            if (32u * w + 32u > b)
+                bits &= 0xFFFFFFFFu >> ((32u - (b & 31u)) & 31u);
+            h += (uint32_t)__popc(bits);
+        }
+        const uint32_t v = r0 + i;
+        const uint32_t f = in_flags[v];
         uint32_t o = 0;
         if (f & MCX_F_LOADED) {
             if (h)
@@ -377,6 +471,33 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
             order.clear();
         }
     }
+    /* slices for the LDS variant of K2a: one per CU, about E / #CU edges each */
+    std::vector<uint32_t> cu_part;
+    uint32_t cu_rows_max = 0, cu_edges_max = 0;
+    {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+        const uint64_t target = (uint64_t)E / (uint64_t)n_cu + 1;
+        const uint32_t rows_cap = 4096; /* 16 KB of row pointers per slice */
+        cu_part.push_back(0);
+        for (uint32_t r = 0; r < V;) {
+            uint32_t end = r;
+            uint64_t load = 0;
+            while (end < V && end - r < rows_cap &&
+                   (end == r || load + (rrow[end + 1] - rrow[end]) <= target)) {
+                load += rrow[end + 1] - rrow[end];
+                ++end;
+            }
+            cu_rows_max = std::max(cu_rows_max, end - r);
+            cu_edges_max = std::max(cu_edges_max, rrow[end] - rrow[r]);
+            cu_part.push_back(end);
+            r = end;
+        }
+        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 4);
+        if (V == 0 || lds > 160 * 1024 - 512)
+            cu_part.clear(); /* does not fit one workgroup: the row-block variant is used */
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     mcx_free_graph(ctx);
     int rc;
@@ -385,6 +506,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         (rc = mcx_dev_upload(ctx, &ctx->d_rrowptr, rrow.data(), (size_t)V + 1)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_rcol, rcol.data(), (size_t)E)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_part, part.data(), part.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_cu_part, cu_part.data(), cu_part.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_lvl_order, order.data(), order.size())) != 0) {
         mcx_free_graph(ctx);
         return rc;
@@ -402,6 +524,16 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     ctx->E = E;
     ctx->n_part = (uint32_t)part.size() - 1u;
     ctx->lvl_ptr = lvl_ptr;
+    ctx->n_cu_part = cu_part.empty() ? 0u : (uint32_t)cu_part.size() - 1u;
+    ctx->cu_rows_max = cu_rows_max;
+    ctx->cu_edges_max = cu_edges_max;
+    if (ctx->n_cu_part) {
+        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 4);
+        hipError_t ea = hipFuncSetAttribute((const void *)k2_flags_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds);
+        if (ea != hipSuccess)
+            ctx->n_cu_part = 0;
+    }
     ctx->graph_loaded = true;
     return MCX_OK;
 }
@@ -420,9 +552,17 @@ int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, v
     uint32_t *bm = ctx->d_queue[0];
     k2_loaded_bitmap<<<(ctx->V + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
         (const uint8_t *)d_in_flags, ctx->V, bm);
-    k2_flags_rows<<<ctx->n_part, K2_THREADS, 0, ctx->stream>>>(ctx->d_rrowptr, ctx->d_rcol, ctx->d_part,
-                                                              (const uint8_t *)d_in_flags, bm,
-                                                              (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
+    if (ctx->n_cu_part) {
+        const uint32_t W = (ctx->V + 31u) / 32u;
+        const size_t lds = 4 * ((size_t)W + ctx->cu_rows_max + 1 + ctx->cu_edges_max / 32 + 4);
+        k2_flags_lds<<<ctx->n_cu_part, K2L_THREADS, lds, ctx->stream>>>(
+            ctx->d_rrowptr, ctx->d_rcol, ctx->d_cu_part, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
+            (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
+    } else {
+        k2_flags_rows<<<ctx->n_part, K2_THREADS, 0, ctx->stream>>>(ctx->d_rrowptr, ctx->d_rcol, ctx->d_part,
+                                                                  (const uint8_t *)d_in_flags, bm,
+                                                                  (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
+    }
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
 }

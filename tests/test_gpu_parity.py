@@ -230,6 +230,16 @@ def test_k2_full_size(gpu_ctx, oracle_mod):
     assert not viol.any()
 
 
+def test_k2_graph_too_large_for_lds_bitmap(gpu_ctx, oracle_mod):
+    """1.5M modules: the LOADED bitmap (187 KB) no longer fits one workgroup's LDS, so the
+    flags come from the row-block kernel instead of the one-block-per-CU kernel"""
+    V = 1_500_000
+    rowptr, col = synth.dep_graph(8, V, 4)
+    flags = synth.dep_flags(8, rowptr, col)
+    seeds, _ = synth.seed_bitmap(8, flags, 4)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
+
+
 def test_k1_normalize_dash_on_device(gpu_ctx, oracle_mod):
     """kmod's '-' -> '_' rule applied to the queried strings by the kernel: dashes in
     and outside brackets, unmatched brackets (unresolvable), bracket pairs that cross
