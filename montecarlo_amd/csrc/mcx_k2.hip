@@ -42,16 +42,30 @@
 /* LOADED bits of in_flags packed 32 modules to a word: the per-edge gather of
  * K2a then reads a 125 KB array (V = 10^6) that stays in cache, not V bytes */
 __global__ void __launch_bounds__(K2_THREADS)
-k2_loaded_bitmap(const uint8_t *__restrict__ in_flags, uint32_t V, uint32_t *__restrict__ bm)
+k2_loaded_bitmap(const uint8_t *__restrict__ in_flags, uint32_t V, uint32_t aligned16,
+                 uint32_t *__restrict__ bm)
 {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = v < V && (in_flags[v] & MCX_F_LOADED);
-    const unsigned long long m = __ballot(on);
-    const uint32_t lane = threadIdx.x & 63u;
-    if (lane == 0u && v < V)
-        bm[v >> 5] = (uint32_t)m;
-    if (lane == 32u && v < V)
-        bm[v >> 5] = (uint32_t)(m >> 32);
+    /* one thread per bitmap word: 32 flag bytes by two 16-byte loads */
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t v0 = 32u * w;
+    if (v0 >= V)
+        return;
+    uint32_t bits = 0;
+    if (aligned16 && v0 + 32u <= V) {
+        const uint4 *src = (const uint4 *)(in_flags + v0);
+        const uint4 lo = src[0], hi = src[1];
+        const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            /* LOADED is bit 0 of every byte: gather the four of them */
+            const uint32_t m = q[k] & 0x01010101u;
+            bits |= (((m * 0x10204080u) >> 28) & 0xFu) << (4u * k);
+        }
+    } else {
+        for (uint32_t k = 0; k < 32u && v0 + k < V; ++k)
+            bits |= (uint32_t)(in_flags[v0 + k] & MCX_F_LOADED) << k;
+    }
+    bm[w] = bits;
 }
 
 __global__ void __launch_bounds__(K2_THREADS)
@@ -550,8 +564,8 @@ int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, v
         return MCX_E_HIP;
     /* the bitmap lives in the first frontier queue (V words, idle outside a closure) */
     uint32_t *bm = ctx->d_queue[0];
-    k2_loaded_bitmap<<<(ctx->V + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
-        (const uint8_t *)d_in_flags, ctx->V, bm);
+    k2_loaded_bitmap<<<((ctx->V + 31u) / 32u + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
+        (const uint8_t *)d_in_flags, ctx->V, ((uintptr_t)d_in_flags & 15u) == 0u ? 1u : 0u, bm);
     if (ctx->n_cu_part) {
         const uint32_t W = (ctx->V + 31u) / 32u;
         const size_t lds = 4 * ((size_t)W + ctx->cu_rows_max + 1 + ctx->cu_edges_max / 32 + 4);
