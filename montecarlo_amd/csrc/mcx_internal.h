@@ -54,7 +54,9 @@ struct mcx_ctx {
     uint32_t *d_cu_part = nullptr;
     uint32_t n_cu_part = 0, cu_rows_max = 0, cu_edges_max = 0;
     uint32_t *d_queue[2] = {nullptr, nullptr}; /* BFS frontiers, V entries each */
-    uint32_t *d_bfs = nullptr;     /* per-level frontier sizes + edge counter  */
+    uint32_t *d_bfs = nullptr;     /* BFS counters, then two hub lists of hub_cap entries, then two hub bitmaps */
+    uint32_t n_hub[2] = {0, 0};    /* modules with a long adjacency list, per closure direction */
+    uint32_t hub_cap = 0;
     uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */
 
     /* holder levels of the graph (fleet pipeline): level 0 = modules nobody

@@ -250,16 +250,25 @@ k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ 
 /* K2b: level-synchronous frontier BFS.                                       */
 /* ------------------------------------------------------------------------- */
 
-/* counters: qsize[level] = vertices in the frontier of that level (zeroed once
- * per call), followed by one 64-bit count of adjacency entries scanned */
+/*
+ * Counters of a search: cnt[2 * level] = vertices in the frontier of that
+ * level, cnt[2 * level + 1] = hubs of that level (vertices with more than
+ * K2B_HUB adjacency entries, kept in a list of their own), all zeroed once per
+ * call; then one 64-bit count of adjacency entries scanned.
+ */
+#define K2B_HUB 256u   /* longer adjacency lists are cut into pieces ...      */
+#define K2B_PIECE 512u /* ... of this many entries, dealt out over the grid  */
+
 struct k2b_state_t {
-    uint32_t *qsize;              /* K2B_MAX_LEVELS + 1 words */
+    uint32_t *cnt;
     unsigned long long *edges;
+    const uint32_t *hubbits; /* bit v = v is a hub in this direction; nullptr = there is none */
+    uint32_t *hubq[2];       /* hubs of the even / odd levels */
 };
 
 __global__ void __launch_bounds__(K2_THREADS)
 k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags, uint32_t V,
-         uint32_t *__restrict__ out, uint32_t *__restrict__ queue, uint32_t *__restrict__ qsize0)
+         uint32_t *__restrict__ out, uint32_t *__restrict__ queue, k2b_state_t st)
 {
     /* one thread per bitmap word: the result word is the seed word restricted
      * to loaded modules, written whole, so the bitmap needs no clearing */
@@ -277,6 +286,15 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
                 keep |= 1u << b;
         }
         out[w] = keep;
+        if (st.hubbits && keep) {
+            uint32_t hub = keep & st.hubbits[w];
+            keep &= ~hub;
+            while (hub) { /* rare */
+                const uint32_t b = (uint32_t)__builtin_ctz(hub);
+                hub &= hub - 1u;
+                st.hubq[0][atomicAdd(&st.cnt[1], 1u)] = 32u * w + b;
+            }
+        }
     }
     /* one queue reservation per wave: exclusive scan of the per-lane counts */
     const uint32_t mine = (uint32_t)__popc(keep);
@@ -292,7 +310,7 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
         return;
     uint32_t at = 0;
     if (lane == 0)
-        at = atomicAdd(qsize0, total);
+        at = atomicAdd(&st.cnt[0], total);
     at = __shfl(at, 0, 64) + incl - mine;
     while (keep) {
         const uint32_t b = (uint32_t)__builtin_ctz(keep);
@@ -301,99 +319,206 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
     }
 }
 
-/* claim u for the closure; true if this call set its bit */
-__device__ __forceinline__ bool k2b_claim(uint32_t *out, const uint8_t *in_flags, uint32_t u)
+/*
+ * One level, edge-parallel.  A wave takes 64 frontier vertices, lays their
+ * adjacency lists end to end (exclusive scan of the degrees, kept in LDS) and
+ * then walks that concatenation 256 entries a step, four per lane: the owner
+ * of entry j is found by bisection in the 64 scan values, the four neighbour
+ * ids, their state bytes and their bitmap words are each requested together,
+ * so a step costs three memory round trips whatever the degrees are.  New
+ * vertices wait in a per-wave LDS buffer and are appended to the next frontier
+ * with one queue reservation per buffer.
+ *
+ * A hub (10^4 holders and more are common: the core modules everything needs)
+ * would keep its wave busy long after the rest of the level is done.  Hubs are
+ * known when the graph is loaded (a bitmap per direction); a newly found hub
+ * goes to the hub list of the next level instead of its frontier, and every
+ * level first walks its frontier and then the lists of its hubs cut into
+ * pieces of K2B_PIECE entries, piece g going to wave g of the grid.
+ */
+#define K2B_PER_LANE 4u
+#define K2B_BUF 1024u
+#ifndef K2B_GMIN
+#define K2B_GMIN 8u
+#endif
+
+/* append a wave's buffered vertices to the next frontier: one reservation */
+__device__ __forceinline__ void k2b_flush(const uint32_t *buf, uint32_t n, uint32_t *__restrict__ next,
+                                          uint32_t *nsize, uint32_t lane)
 {
-    if (!(in_flags[u] & MCX_F_LOADED))
-        return false;
-    const uint32_t bit = 1u << (u & 31u);
-    if (out[u >> 5] & bit)
-        return false;
-    return !(atomicOr(&out[u >> 5], bit) & bit);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t at = 0;
+    if (lane == 0)
+        at = atomicAdd(nsize, n);
+    at = __shfl(at, 0, 64);
+    for (uint32_t i = lane; i < n; i += 64u)
+        next[at + i] = buf[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-/*
- * One level.  A frontier vertex with fewer than 32 neighbours is expanded by
- * its own lane; the others are taken one at a time by the whole wave, which
- * then reads the adjacency 64 entries per step (a hub with 10^4 holders would
- * otherwise keep one lane busy for 10^4 steps).  New vertices are appended to
- * the next frontier with one queue reservation per wave step.
- */
 __global__ void __launch_bounds__(K2_THREADS)
 k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
            const uint8_t *__restrict__ in_flags, const uint32_t *__restrict__ frontier,
            uint32_t *__restrict__ out, uint32_t *__restrict__ next, k2b_state_t st, uint32_t level)
 {
-    const uint32_t n = st.qsize[level];
-    if (n == 0u)
+    __shared__ uint32_t pre[K2_THREADS / 64][65];
+    __shared__ uint32_t beg[K2_THREADS / 64][64];
+    __shared__ uint32_t buf[K2_THREADS / 64][K2B_BUF];
+    uint32_t nbuf = 0; /* the same in all lanes of a wave */
+    const uint32_t n = st.cnt[2u * level], nh = st.cnt[2u * level + 1u];
+    if (n == 0u && nh == 0u)
         return;
-    uint32_t *nsize = &st.qsize[level + 1u];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t *nsize = &st.cnt[2u * level + 2u], *nhub = &st.cnt[2u * level + 3u];
+    const uint32_t *hubbits = st.hubbits;
+    uint32_t *nexthubs = st.hubq[(level + 1u) & 1u];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long scanned = 0;
-    /* all lanes of a wave run the same number of rounds */
-    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t base = first - lane; base < n; base += stride) {
+
+    /* the neighbours u[] of one step: state byte, bitmap word, claim, buffer */
+    auto visit = [&](const uint32_t (&u)[K2B_PER_LANE], const bool (&have)[K2B_PER_LANE])
+                     __attribute__((always_inline)) {
+        uint32_t f[K2B_PER_LANE], w[K2B_PER_LANE], hb[K2B_PER_LANE];
+#pragma unroll
+        for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
+            f[q] = have[q] ? in_flags[u[q]] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
+            const bool loaded = (f[q] & MCX_F_LOADED) != 0u;
+            w[q] = loaded ? out[u[q] >> 5] : 0xFFFFFFFFu;
+            hb[q] = (hubbits && loaded) ? hubbits[u[q] >> 5] : 0u;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
+            const uint32_t bit = 1u << (u[q] & 31u);
+            bool got = false;
+            if (!(w[q] & bit))
+                got = !(atomicOr(&out[u[q] >> 5], bit) & bit);
+            if (got && (hb[q] & bit)) { /* rare */
+                nexthubs[atomicAdd(nhub, 1u)] = u[q];
+                got = false;
+            }
+            const unsigned long long m = __ballot(got);
+            if (m) {
+                if (got)
+                    buf[wave][nbuf + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = u[q];
+                nbuf += (uint32_t)__popcll(m);
+            }
+        }
+        if (nbuf > K2B_BUF - 64u * K2B_PER_LANE) {
+            k2b_flush(buf[wave], nbuf, next, nsize, lane);
+            nbuf = 0;
+        }
+    };
+
+    /* the frontier, `grp` vertices per wave and round: 64 when there is enough
+     * of it for the whole grid, fewer (down to K2B_GMIN) when there is not, so
+     * that a short frontier of long lists still spreads over many waves */
+    const uint32_t nwaves_all = gridDim.x * (K2_THREADS / 64u);
+    uint32_t grp = 64u;
+    while (grp > K2B_GMIN && (grp >> 1) * nwaves_all >= n)
+        grp >>= 1;
+    const uint32_t wave_all = blockIdx.x * (K2_THREADS / 64u) + wave;
+    for (uint32_t base = wave_all * grp; base < n; base += nwaves_all * grp) {
         const uint32_t t = base + lane;
         uint32_t k0 = 0, k1 = 0;
-        if (t < n) {
+        if (lane < grp && t < n) {
             const uint32_t v = frontier[t];
             k0 = rowptr[v];
             k1 = rowptr[v + 1];
-            scanned += k1 - k0;
         }
-        const bool big = (k1 - k0) >= 32u;
-        /* short adjacency lists: one entry per lane and step, the new
-         * vertices of a step appended with one queue reservation per wave */
-        {
-            uint32_t k = big ? k1 : k0;
-            while (__any(k < k1)) {
-                bool got = false;
-                uint32_t u = 0;
-                if (k < k1) {
-                    u = col[k];
-                    got = k2b_claim(out, in_flags, u);
-                    ++k;
+        const uint32_t deg = k1 - k0;
+        scanned += deg;
+        uint32_t incl = deg;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d)
+                incl += o;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        pre[wave][lane] = incl - deg;
+        beg[wave][lane] = k0;
+        if (lane == 63u)
+            pre[wave][64] = total;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t j0 = 0; j0 < total; j0 += 64u * K2B_PER_LANE) {
+            uint32_t u[K2B_PER_LANE];
+            bool have[K2B_PER_LANE];
+#pragma unroll
+            for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
+                const uint32_t j = j0 + 64u * q + lane;
+                have[q] = j < total;
+                uint32_t lo = 0, hi = 64; /* largest i with pre[i] <= j */
+#pragma unroll
+                for (uint32_t step = 0; step < 6u; ++step) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pre[wave][mid] <= j)
+                        lo = mid;
+                    else
+                        hi = mid;
                 }
-                const unsigned long long m = __ballot(got);
-                if (m) {
-                    uint32_t at = 0;
-                    if (lane == 0)
-                        at = atomicAdd(nsize, (uint32_t)__popcll(m));
-                    at = __shfl(at, 0, 64);
-                    if (got)
-                        next[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = u;
-                }
+                u[q] = have[q] ? col[beg[wave][lo] + (j - pre[wave][lo])] : 0u;
             }
+            visit(u, have);
         }
-        /* long ones: the wave takes them in turn */
-        unsigned long long todo = __ballot(big);
-        while (todo) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const uint32_t b0 = __shfl(k0, src, 64), b1 = __shfl(k1, src, 64);
-            for (uint32_t kb = b0; kb < b1; kb += 64u) {
-                const uint32_t k = kb + lane;
-                bool got = false;
-                uint32_t u = 0;
-                if (k < b1) {
-                    u = col[k];
-                    got = k2b_claim(out, in_flags, u);
-                }
-                const unsigned long long m = __ballot(got);
-                if (m) {
-                    uint32_t at = 0;
-                    if (lane == 0)
-                        at = atomicAdd(nsize, (uint32_t)__popcll(m));
-                    at = __shfl(at, 0, 64);
-                    if (got)
-                        next[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = u;
+        /* pre / beg are rewritten by the next round */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    /* the hubs of this level, 64 at a time: piece g of their lists laid end to
+     * end goes to wave g, counted from the far end of the grid (the near end
+     * holds the frontier when that is short) */
+    if (nh) {
+        const uint32_t *hubs = st.hubq[level & 1u];
+        const uint32_t nwaves = gridDim.x * (K2_THREADS / 64u);
+        const uint32_t gwave = nwaves - 1u - (blockIdx.x * (K2_THREADS / 64u) + wave);
+        for (uint32_t h0 = 0; h0 < nh; h0 += 64u) {
+            uint32_t k0 = 0, k1 = 0;
+            if (h0 + lane < nh) {
+                const uint32_t v = hubs[h0 + lane];
+                k0 = rowptr[v];
+                k1 = rowptr[v + 1];
+            }
+            if (gwave == 0u)
+                scanned += k1 - k0;
+            const uint32_t np = (k1 - k0 + K2B_PIECE - 1u) / K2B_PIECE;
+            uint32_t incl = np;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d)
+                    incl += o;
+            }
+            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t excl = incl - np;
+            for (uint32_t g = gwave; g < total; g += nwaves) {
+                /* lanes without a hub have excl = total > g */
+                const uint32_t idx = (uint32_t)__popcll(__ballot(np != 0u && excl <= g)) - 1u;
+                const uint32_t ks = __shfl(k0, idx, 64) + (g - __shfl(excl, idx, 64)) * K2B_PIECE;
+                const uint32_t ke = min(ks + K2B_PIECE, __shfl(k1, idx, 64));
+                for (uint32_t j0 = ks; j0 < ke; j0 += 64u * K2B_PER_LANE) {
+                    uint32_t u[K2B_PER_LANE];
+                    bool have[K2B_PER_LANE];
+#pragma unroll
+                    for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
+                        const uint32_t j = j0 + 64u * q + lane;
+                        have[q] = j < ke;
+                        u[q] = have[q] ? col[j] : 0u;
+                    }
+                    visit(u, have);
                 }
             }
         }
     }
+    if (nbuf)
+        k2b_flush(buf[wave], nbuf, next, nsize, lane);
     /* one add per wave */
 #pragma unroll
     for (uint32_t d = 32; d >= 1; d >>= 1)
@@ -401,6 +526,9 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
     if (lane == 0 && scanned)
         atomicAdd(st.edges, scanned);
 }
+
+/* words of BFS state cleared per call: the per-level counters and the edge count */
+#define K2B_STATE_WORDS (2u * (K2B_MAX_LEVELS + 1u) + 2u)
 
 /* ------------------------------------------------------------------------- */
 /* C ABI                                                                      */
@@ -512,6 +640,21 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         if (V == 0 || lds > 160 * 1024 - 512)
             cu_part.clear(); /* does not fit one workgroup: the row-block variant is used */
     }
+    /* hubs of the closure search, per direction: bit v of words [d * W, (d + 1) * W) */
+    const uint32_t W = (V + 31u) / 32u;
+    std::vector<uint32_t> hubbits((size_t)2 * W + 1, 0);
+    uint32_t n_hub[2] = {0, 0};
+    for (uint32_t v = 0; v < V; ++v) {
+        if (rrow[(size_t)v + 1] - rrow[v] > K2B_HUB) {
+            hubbits[v >> 5] |= 1u << (v & 31u);
+            ++n_hub[MCX_CLOSURE_HOLDERS];
+        }
+        if (rowptr[v + 1] - rowptr[v] > K2B_HUB) {
+            hubbits[(size_t)W + (v >> 5)] |= 1u << (v & 31u);
+            ++n_hub[MCX_CLOSURE_DEPS];
+        }
+    }
+    const uint32_t hub_cap = std::max(n_hub[0], n_hub[1]);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     mcx_free_graph(ctx);
     int rc;
@@ -528,11 +671,18 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     size_t vb = 4 * ((size_t)V ? V : 1);
     if (hipMalloc((void **)&ctx->d_queue[0], vb) != hipSuccess ||
         hipMalloc((void **)&ctx->d_queue[1], vb) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_bfs, 4 * (size_t)(K2B_MAX_LEVELS + 4)) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_bfs, 4 * ((size_t)K2B_STATE_WORDS + 2 * (size_t)hub_cap + 2 * (size_t)W + 1)) !=
+            hipSuccess) {
         mcx_free_graph(ctx);
         ctx->err = "hipMalloc of graph scratch failed";
         return MCX_E_NOMEM;
     }
+    /* BFS state, the two hub lists, the two hub bitmaps */
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_bfs + K2B_STATE_WORDS + 2 * (size_t)hub_cap, hubbits.data(),
+                               4 * ((size_t)2 * W + 1), hipMemcpyHostToDevice, ctx->stream));
+    ctx->n_hub[0] = n_hub[0];
+    ctx->n_hub[1] = n_hub[1];
+    ctx->hub_cap = hub_cap;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->V = V;
     ctx->E = E;
@@ -638,18 +788,21 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     const uint32_t *cl = direction == MCX_CLOSURE_HOLDERS ? ctx->d_rcol : ctx->d_col;
     const uint32_t W = (V + 31) / 32;
     k2b_state_t st;
-    st.qsize = ctx->d_bfs;
-    st.edges = (unsigned long long *)(ctx->d_bfs + K2B_MAX_LEVELS + 2); /* 8-byte aligned */
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_bfs, 0, 4 * (size_t)(K2B_MAX_LEVELS + 4), ctx->stream));
+    st.cnt = ctx->d_bfs;
+    st.edges = (unsigned long long *)(ctx->d_bfs + K2B_STATE_WORDS - 2u); /* 8-byte aligned */
+    st.hubq[0] = ctx->d_bfs + K2B_STATE_WORDS;
+    st.hubq[1] = st.hubq[0] + ctx->hub_cap;
+    st.hubbits = ctx->n_hub[direction] ? st.hubq[1] + ctx->hub_cap + (size_t)direction * W : nullptr;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_bfs, 0, 4 * (size_t)K2B_STATE_WORDS, ctx->stream));
     k2b_seed<<<(W + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
         (const uint32_t *)d_seed_bitmap, (const uint8_t *)d_in_flags, V, (uint32_t *)d_out_bitmap,
-        ctx->d_queue[0], &st.qsize[0]);
+        ctx->d_queue[0], st);
     /* levels are enqueued K2B_BATCH at a time; a level whose frontier is empty
      * returns at once, and the queue sizes of a batch tell where the search
      * ended.  A path visits each vertex once, so V levels always suffice. */
     uint32_t lv = 0;
-    uint32_t *sizes = ctx->h_pinned;                                  /* K2B_BATCH words */
-    unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 16);
+    uint32_t *sizes = ctx->h_pinned;                                  /* 2 * K2B_BATCH words */
+    unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 2 * K2B_BATCH);
     bool done = false;
     while (!done) {
         if (lv + K2B_BATCH > K2B_MAX_LEVELS) {
@@ -664,11 +817,11 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                                                                   ctx->d_queue[(level + 1u) & 1u], st, level);
         }
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(sizes, &st.qsize[lv], 4 * K2B_BATCH, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(sizes, &st.cnt[2u * lv], 8 * K2B_BATCH, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(h_edges, st.edges, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (uint32_t b = 0; b < K2B_BATCH; ++b) {
-            if (sizes[b] == 0u) {
+            if (sizes[2u * b] == 0u && sizes[2u * b + 1u] == 0u) {
                 done = true;
                 break;
             }

@@ -205,6 +205,42 @@ def test_k2_hand_graphs(gpu_ctx, oracle_mod):
     gpu_ctx.dep_graph_load(np.zeros(1, np.uint32), np.zeros(0, np.uint32))
 
 
+def test_k2_hubs(gpu_ctx, oracle_mod):
+    """modules with very long adjacency lists in both directions (the closure cuts
+    those lists into pieces dealt over the grid): hubs as seeds, hubs found at a
+    later level, several hubs in one level, and a 20000-seed closure"""
+    rng = np.random.default_rng(77)
+    V = 60000
+    edges = set()
+    for hub in (0, 1, 2, 40000):                     # needed by thousands of modules
+        for u in rng.choice(np.arange(100, V), size=int(rng.integers(3000, 20000)), replace=False):
+            if u != hub:
+                edges.add((int(u), hub))
+    for fat in (50, 51, 59999):                      # modules that need thousands of others
+        for v in rng.choice(np.arange(100, V - 1), size=int(rng.integers(1000, 9000)), replace=False):
+            if v != fat:
+                edges.add((fat, int(v)))
+    edges.add((40000, 50))                           # hub reached through a chain
+    edges.add((0, 40000))
+    for u in rng.integers(100, V, size=100000):
+        v = int(rng.integers(0, V))
+        if v != int(u):
+            edges.add((int(u), v))
+    e = np.array(sorted(edges), dtype=np.uint32)
+    rowptr = np.zeros(V + 1, dtype=np.uint32)
+    np.add.at(rowptr, e[:, 0].astype(np.int64) + 1, 1)
+    rowptr = np.cumsum(rowptr, dtype=np.uint64).astype(np.uint32)
+    col = np.ascontiguousarray(e[:, 1])
+    flags = np.where(rng.random(V) < 0.9, 5, 4).astype(np.uint8)
+    flags[[0, 1, 2, 50, 51, 40000, 59999]] = 5
+    W = (V + 31) // 32
+    for picks in ([0], [50], [59999], [0, 1, 2, 40000], [12345], list(range(100, 20100))):
+        seeds = np.zeros(W, dtype=np.uint32)
+        for v in picks:
+            seeds[v >> 5] |= np.uint32(1 << (v & 31))
+        check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
+
+
 def test_k2_full_size(gpu_ctx, oracle_mod):
     """configs[2]: 1M modules, ~10M edges.  The oracle still finishes in seconds, so
     this is a direct comparison plus the closure properties (idempotence, seeds
