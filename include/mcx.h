@@ -222,6 +222,101 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
                         void *d_root_off, void *d_root_ids, uint64_t cap,
                         uint64_t *total_out);
 
+/* ---- fleet inventory: which devices a host would list --------------------- */
+
+/*
+ * mc_list_all_devices (montecarlo/libmontecarlo.c:233-440) walks one host's
+ * sysfs and drops bridges, hubs, host controllers and SCSI scaffolding
+ * (mc_is_infrastructure_device, montecarlo/libmontecarlo.c:729-823) before a
+ * device reaches the list; mc_is_excluded_device
+ * (montecarlo/libmontecarlo.c:826-874) marks USB mass storage.  For an
+ * inventory of many hosts the same tests run over packed records, one per
+ * device, holding what those functions read from sysfs.
+ */
+#define MCX_SUB_USB 0u     /* subsystem, the five of libmontecarlo.c:247 */
+#define MCX_SUB_PCI 1u
+#define MCX_SUB_HID 2u
+#define MCX_SUB_SCSI 3u
+#define MCX_SUB_PCMCIA 4u
+#define MCX_SUB_OTHER 255u /* anything else: never enumerated */
+
+#define MCX_DT_NONE 0u /* udev devtype */
+#define MCX_DT_USB_DEVICE 1u
+#define MCX_DT_USB_INTERFACE 2u
+#define MCX_DT_SCSI_HOST 3u
+#define MCX_DT_SCSI_TARGET 4u
+#define MCX_DT_SCSI_GENERIC 5u
+#define MCX_DT_OTHER 6u /* e.g. scsi_device */
+
+#define MCX_DA_PCI_CLASS 0x01u    /* sysfs "class" is readable: pci_class is valid  */
+#define MCX_DA_IFACE_CLASS 0x02u  /* bInterfaceClass readable: iface_class valid    */
+#define MCX_DA_PARENT 0x04u       /* has a usb / usb_device parent                  */
+#define MCX_DA_PARENT_CLASS 0x08u /* the parent's bDeviceClass: parent_class valid  */
+#define MCX_DA_OWN_CLASS 0x10u    /* the node's own bDeviceClass: own_class valid   */
+#define MCX_DA_SCSI_MODEL 0x20u   /* sysfs "model" readable                         */
+#define MCX_DA_SCSI_VENDOR 0x40u  /* sysfs "vendor" readable                        */
+
+#define MCX_DRV_NONE 0xFFFFFFFFu    /* no driver link: the list shows "None"         */
+#define MCX_DRV_NOSLASH 0xFFFFFFFEu /* a link whose target holds no '/'              */
+
+typedef struct mcx_dev_rec {
+    uint8_t subsystem;    /* MCX_SUB_*                                              */
+    uint8_t devtype;      /* MCX_DT_*                                               */
+    uint8_t attrs;        /* MCX_DA_* presence bits                                 */
+    uint8_t iface_class;  /* bInterfaceClass, the value of its two hex digits       */
+    uint32_t pci_class;   /* the 24-bit class code of sysfs "class" (0xBBSSII)      */
+    uint8_t parent_class; /* bDeviceClass of the usb_device parent                  */
+    uint8_t own_class;    /* bDeviceClass of the node itself                        */
+    uint16_t reserved;
+    uint32_t driver;      /* index into the driver-name table, or MCX_DRV_*         */
+} mcx_dev_rec_t;          /* 16 bytes */
+
+/* verdict byte per device */
+#define MCX_DV_LISTED 0x01u   /* mc_list_all_devices would put it in the list       */
+#define MCX_DV_EXCLUDED 0x02u /* mc_is_excluded_device: USB mass storage            */
+#define MCX_DV_REASON(v) ((v) >> 4) /* why a device is not listed: MCX_DR_*         */
+#define MCX_DR_NONE 0u
+#define MCX_DR_SUBSYSTEM 1u   /* not one of the five subsystems (libmontecarlo.c:393-398) */
+#define MCX_DR_PCI_CLASS 2u   /* bridge, SMBus, system peripheral (:757-762)         */
+#define MCX_DR_PCI_DRIVER 3u  /* one of the 8 port / hot-plug drivers (:773-785)     */
+#define MCX_DR_SCSI 4u        /* host, target, generic, or nameless (:790-818)       */
+#define MCX_DR_USB_NODE 5u    /* not a usb_interface, or without parent (:293-314)   */
+#define MCX_DR_USB_HUB 6u     /* interface or parent class 09 (:301-321)             */
+#define MCX_DR_USB_HOST 7u    /* driver name holds "hcd" or is "hub" (:412-417)      */
+#define MCX_DR_OVER_MAX 8u    /* the host's list was already full (:259-260)         */
+
+/*
+ * verdict[i] for N device records of H hosts (host h owns records
+ * dev_off[h] .. dev_off[h+1]; the order within a host is the enumeration
+ * order).  Driver names are packed like patterns (drv_arena, drv_off, D names).
+ * max_per_host = the `max` argument of mc_list_all_devices (the reference's UI
+ * passes 64, desktop/ui.py:1335; 0 = no limit): only the first max_per_host
+ * devices of a host that pass are listed.  kept_off (H + 1 entries, optional):
+ * prefix sums of the listed devices per host.  The *_dev form takes device
+ * pointers, enqueues, and waits once for *kept_total.
+ */
+int mcx_device_filter(mcx_ctx *ctx, const mcx_dev_rec_t *rec, uint32_t N,
+                      const char *drv_arena, const uint32_t *drv_off, uint32_t D,
+                      const uint32_t *dev_off, uint32_t H, uint32_t max_per_host,
+                      uint8_t *verdict, uint32_t *kept_off);
+int mcx_device_filter_dev(mcx_ctx *ctx, const void *d_rec, uint32_t N,
+                          const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                          const void *d_dev_off, uint32_t H, uint32_t max_per_host,
+                          void *d_verdict, void *d_kept_off, uint64_t *kept_total);
+/*
+ * The listed devices' modalias strings, packed in order, ready for
+ * mcx_alias_match_dev / mcx_fleet_roots_dev with d_kept_off as their dev_off:
+ * string k of the output is string i of the input for the k-th i with
+ * MCX_DV_LISTED set.  d_S_out needs s_off[N] bytes, d_s_off_out kept_total + 1
+ * entries, d_src (optional) kept_total entries and receives the i's.
+ * All pointers are device pointers; d_verdict and d_kept_off are the outputs
+ * of mcx_device_filter_dev for the same records.
+ */
+int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, const void *d_s_off,
+                          uint32_t N, const void *d_dev_off, uint32_t H, const void *d_kept_off,
+                          uint32_t kept_total, void *d_S_out, void *d_s_off_out, void *d_src,
+                          uint64_t *bytes_out);
+
 /* ---- text tables: modules.alias, modules.dep, /proc/modules ------------- */
 
 /*

@@ -24,6 +24,7 @@ from .binding import (  # noqa: F401
     TABLE_NORMALIZE_DASH,
     safe_module_names,
     pack_strings,
+    DEV_REC,
 )
 from . import synth  # noqa: F401
 

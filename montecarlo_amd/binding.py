@@ -17,6 +17,17 @@ O_HAS_HOLDERS, O_IN_USE, O_ROOT = 1, 2, 4
 CLOSURE_HOLDERS, CLOSURE_DEPS = 0, 1
 TABLE_NORMALIZE_DASH = 1
 
+# packed device record of the fleet inventory (mcx_dev_rec_t, 16 bytes)
+DEV_REC = np.dtype([("subsystem", "u1"), ("devtype", "u1"), ("attrs", "u1"), ("iface_class", "u1"),
+                    ("pci_class", "<u4"), ("parent_class", "u1"), ("own_class", "u1"), ("reserved", "<u2"),
+                    ("driver", "<u4")])
+SUB_USB, SUB_PCI, SUB_HID, SUB_SCSI, SUB_PCMCIA, SUB_OTHER = 0, 1, 2, 3, 4, 255
+DT_NONE, DT_USB_DEVICE, DT_USB_INTERFACE, DT_SCSI_HOST, DT_SCSI_TARGET, DT_SCSI_GENERIC, DT_OTHER = range(7)
+DA_PCI_CLASS, DA_IFACE_CLASS, DA_PARENT, DA_PARENT_CLASS, DA_OWN_CLASS, DA_SCSI_MODEL, DA_SCSI_VENDOR = (
+    1, 2, 4, 8, 16, 32, 64)
+DRV_NONE, DRV_NOSLASH = 0xFFFFFFFF, 0xFFFFFFFE
+DV_LISTED, DV_EXCLUDED = 1, 2
+
 _c_u32p = ctypes.POINTER(ctypes.c_uint32)
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
 _vp = ctypes.c_void_p
@@ -111,6 +122,20 @@ def load_library():
         "mcx_fleet_roots": (
             ctypes.c_int,
             [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64,
+             ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_device_filter": (
+            ctypes.c_int,
+            [_vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp],
+        ),
+        "mcx_device_filter_dev": (
+            ctypes.c_int,
+            [_vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp,
+             ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_fleet_compact_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, _vp,
              ctypes.POINTER(ctypes.c_uint64)],
         ),
         "mcx_fleet_roots_dev": (
@@ -361,6 +386,45 @@ class Context:
         if not (size_only and rc == -6 and cap < total.value < 2**32):
             self._check(rc, "mcx_fleet_roots_dev")
         return total.value
+
+
+    # ---- fleet inventory predicates ------------------------------------------
+    def device_filter(self, rec, drv_arena, drv_off, dev_off, max_per_host=0):
+        """(verdict uint8[N], kept_off uint32[H+1]) of mcx_device_filter"""
+        rec = np.ascontiguousarray(rec, dtype=DEV_REC)
+        drv_arena, drv_off, dev_off = _as(drv_arena, np.uint8), _as(drv_off, np.uint32), _as(dev_off, np.uint32)
+        N, H, D = len(rec), len(dev_off) - 1, len(drv_off) - 1
+        verdict = np.zeros(max(N, 1), dtype=np.uint8)
+        kept_off = np.zeros(H + 1, dtype=np.uint32)
+        self._check(
+            self.lib.mcx_device_filter(self.h, _ptr(rec), N, _ptr(drv_arena), _ptr(drv_off), D, _ptr(dev_off), H,
+                                       int(max_per_host), _ptr(verdict), _ptr(kept_off)),
+            "mcx_device_filter",
+        )
+        return verdict[:N], kept_off
+
+    def device_filter_dev(self, d_rec, N, d_drv_arena, d_drv_off, D, d_dev_off, H, max_per_host, d_verdict,
+                          d_kept_off):
+        """returns the number of listed devices"""
+        total = ctypes.c_uint64()
+        self._check(
+            self.lib.mcx_device_filter_dev(self.h, d_rec, N, d_drv_arena, d_drv_off, D, d_dev_off, H,
+                                           int(max_per_host), d_verdict, d_kept_off, ctypes.byref(total)),
+            "mcx_device_filter_dev",
+        )
+        return total.value
+
+    def fleet_compact_dev(self, d_verdict, d_S, d_s_off, N, d_dev_off, H, d_kept_off, kept_total, d_S_out,
+                          d_s_off_out, d_src=None, want_bytes=True):
+        """returns the bytes of the packed strings (None when want_bytes is False: no wait)"""
+        nbytes = ctypes.c_uint64()
+        self._check(
+            self.lib.mcx_fleet_compact_dev(self.h, d_verdict, d_S, d_s_off, N, d_dev_off, H, d_kept_off,
+                                           int(kept_total), d_S_out, d_s_off_out, d_src,
+                                           ctypes.byref(nbytes) if want_bytes else None),
+            "mcx_fleet_compact_dev",
+        )
+        return nbytes.value if want_bytes else None
 
 
 def safe_module_names(names):

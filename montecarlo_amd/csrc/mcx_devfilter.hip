@@ -1,0 +1,331 @@
+/*
+ * mcx_devfilter.hip - which devices of a fleet inventory a host's device list
+ * would show, and the packing of their modalias strings for the alias match.
+ *
+ * Restates, over packed records, the tests that mc_list_all_devices
+ * (reference montecarlo/libmontecarlo.c:233-440) and
+ * mc_is_infrastructure_device (montecarlo/libmontecarlo.c:729-823) make on one
+ * sysfs node at a time, plus mc_is_excluded_device
+ * (montecarlo/libmontecarlo.c:826-874).  Byte and integer work, bound by the
+ * stream of records and strings through HBM:
+ *
+ *   dv_names      one thread per driver name: the two name tests, once
+ *   dv_classify   one thread per 16-byte record -> verdict byte
+ *   dv_host<0>    one wave per host: rank of each passing device in its host,
+ *                 the per-host limit, the host's count
+ *   scan          counts -> kept_off
+ *   dv_host<1>    one wave per host: source index and length of every kept string
+ *   scan          lengths -> s_off_out
+ *   dv_copy       16 lanes per kept string: the bytes
+ */
+#include <string.h>
+
+#include "mcx_internal.h"
+#include "mcx_scan.h"
+
+#define DVN_INFRA 1u   /* one of the 8 PCI port / hot-plug drivers */
+#define DVN_USBHOST 2u /* holds "hcd" or is "hub" */
+
+/* montecarlo/libmontecarlo.c:778-780 */
+__constant__ char dv_infra_names[8][12] = {"pcieport", "pci_bridge", "pciehp",  "pcie_aspm",
+                                           "pcie_pme", "pcie_edr",   "shpchp", "piix4_smbus"};
+
+__global__ void __launch_bounds__(FL_THREADS)
+dv_names(const char *__restrict__ arena, const uint32_t *__restrict__ off, uint32_t D, uint8_t *__restrict__ bits)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D)
+        return;
+    const char *s = arena + off[d];
+    const uint32_t n = off[d + 1] - off[d];
+    uint32_t b = 0;
+    for (uint32_t k = 0; k < 8u; ++k) {
+        uint32_t i = 0;
+        while (i < n && dv_infra_names[k][i] != '\0' && dv_infra_names[k][i] == s[i])
+            ++i;
+        if (i == n && dv_infra_names[k][i] == '\0')
+            b |= DVN_INFRA;
+    }
+    /* strstr(name, "hcd") || strcmp(name, "hub") == 0   (libmontecarlo.c:413) */
+    for (uint32_t i = 0; i + 3u <= n; ++i)
+        if (s[i] == 'h' && s[i + 1] == 'c' && s[i + 2] == 'd')
+            b |= DVN_USBHOST;
+    if (n == 3u && s[0] == 'h' && s[1] == 'u' && s[2] == 'b')
+        b |= DVN_USBHOST;
+    bits[d] = (uint8_t)b;
+}
+
+__device__ __forceinline__ uint32_t dv_verdict(const uint4 r, const uint8_t *__restrict__ drv_bits, uint32_t D)
+{
+    const uint32_t sub = r.x & 0xFFu, devtype = (r.x >> 8) & 0xFFu, attrs = (r.x >> 16) & 0xFFu;
+    const uint32_t iface_class = r.x >> 24, pci_class = r.y;
+    const uint32_t parent_class = r.z & 0xFFu, own_class = (r.z >> 8) & 0xFFu, driver = r.w;
+    const uint32_t nbits = driver < D ? drv_bits[driver] : 0u;
+
+    /* mc_is_excluded_device: class 08 on the node, the interface or the parent */
+    uint32_t v = 0;
+    if (((attrs & MCX_DA_OWN_CLASS) && own_class == 8u) || ((attrs & MCX_DA_IFACE_CLASS) && iface_class == 8u) ||
+        ((attrs & MCX_DA_PARENT) && (attrs & MCX_DA_PARENT_CLASS) && parent_class == 8u))
+        v |= MCX_DV_EXCLUDED;
+
+    uint32_t why = MCX_DR_NONE;
+    if (sub == MCX_SUB_PCI) {
+        const uint32_t base = (pci_class >> 16) & 0xFFu, subc = (pci_class >> 8) & 0xFFu;
+        if ((attrs & MCX_DA_PCI_CLASS) && (base == 0x06u || (base == 0x0Cu && subc == 0x05u) || base == 0x08u))
+            why = MCX_DR_PCI_CLASS;
+        else if (driver == MCX_DRV_NOSLASH || (nbits & DVN_INFRA))
+            why = MCX_DR_PCI_DRIVER;
+    } else if (sub == MCX_SUB_SCSI) {
+        if (devtype == MCX_DT_NONE || devtype == MCX_DT_SCSI_HOST || devtype == MCX_DT_SCSI_TARGET ||
+            devtype == MCX_DT_SCSI_GENERIC || !(attrs & (MCX_DA_SCSI_MODEL | MCX_DA_SCSI_VENDOR)))
+            why = MCX_DR_SCSI;
+    } else if (sub == MCX_SUB_USB) {
+        if (devtype != MCX_DT_USB_INTERFACE)
+            why = MCX_DR_USB_NODE;
+        else if ((attrs & MCX_DA_IFACE_CLASS) && iface_class == 9u)
+            why = MCX_DR_USB_HUB;
+        else if (!(attrs & MCX_DA_PARENT))
+            why = MCX_DR_USB_NODE;
+        else if ((attrs & MCX_DA_PARENT_CLASS) && parent_class == 9u)
+            why = MCX_DR_USB_HUB;
+        else if (nbits & DVN_USBHOST)
+            why = MCX_DR_USB_HOST;
+    } else if (sub != MCX_SUB_HID && sub != MCX_SUB_PCMCIA) {
+        why = MCX_DR_SUBSYSTEM;
+    }
+    return why == MCX_DR_NONE ? (v | MCX_DV_LISTED) : (v | (why << 4));
+}
+
+__global__ void __launch_bounds__(FL_THREADS)
+dv_classify(const uint4 *__restrict__ rec, uint32_t N, const uint8_t *__restrict__ drv_bits, uint32_t D,
+            uint8_t *__restrict__ verdict)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N)
+        verdict[i] = (uint8_t)dv_verdict(rec[i], drv_bits, D);
+}
+
+/*
+ * One wave per host, its devices 64 at a time in enumeration order.
+ * FILL = 0: apply the per-host limit to the verdicts and count the host's
+ * listed devices.  FILL = 1: for the r-th listed device of host h write its
+ * index and string length at kept_off[h] + r.
+ */
+template <int FILL>
+__global__ void __launch_bounds__(FL_THREADS)
+dv_host(const uint32_t *__restrict__ dev_off, uint32_t H, uint32_t max_per_host, uint8_t *verdict,
+        uint32_t *__restrict__ cnt, const uint32_t *__restrict__ kept_off, const uint32_t *__restrict__ s_off,
+        uint32_t *__restrict__ src, uint32_t *__restrict__ len)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (h >= H)
+        return;
+    const uint32_t b = dev_off[h], e = dev_off[h + 1];
+    const uint32_t base = FILL ? kept_off[h] : 0u;
+    uint32_t running = 0;
+    for (uint32_t i0 = b; i0 < e; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t v = i < e ? verdict[i] : 0u;
+        const bool keep = (v & MCX_DV_LISTED) != 0u;
+        const unsigned long long m = __ballot(keep);
+        const uint32_t r = running + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (FILL) {
+            if (keep) {
+                src[base + r] = i;
+                len[base + r] = s_off[i + 1] - s_off[i];
+            }
+        } else if (keep && max_per_host && r >= max_per_host) {
+            verdict[i] = (uint8_t)((v & MCX_DV_EXCLUDED) | (MCX_DR_OVER_MAX << 4));
+        }
+        running += (uint32_t)__popcll(m);
+    }
+    if (!FILL && lane == 0u)
+        cnt[h] = (max_per_host && running > max_per_host) ? max_per_host : running;
+}
+
+/* 16 lanes per kept string */
+__global__ void __launch_bounds__(FL_THREADS)
+dv_copy(const char *__restrict__ S, const uint32_t *__restrict__ s_off, const uint32_t *__restrict__ src,
+        const uint32_t *__restrict__ s_off_out, uint32_t K, char *__restrict__ S_out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = t >> 4, sub = t & 15u;
+    if (k >= K)
+        return;
+    const uint32_t from = s_off[src[k]], to = s_off_out[k], n = s_off_out[k + 1] - to;
+    for (uint32_t b = sub; b < n; b += 16u)
+        S_out[to + b] = S[from + b];
+}
+
+extern "C" {
+
+int mcx_device_filter_dev(mcx_ctx *ctx, const void *d_rec, uint32_t N, const void *d_drv_arena,
+                          const void *d_drv_off, uint32_t D, const void *d_dev_off, uint32_t H,
+                          uint32_t max_per_host, void *d_verdict, void *d_kept_off, uint64_t *kept_total)
+{
+    if (!ctx || !d_dev_off || (N && (!d_rec || !d_verdict)) || (D && !d_drv_off))
+        return MCX_E_BAD_ARG;
+    if (kept_total)
+        *kept_total = 0;
+    if ((uintptr_t)d_rec & 15u) {
+        ctx->err = "device records must be 16-byte aligned";
+        return MCX_E_BAD_ARG;
+    }
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    if (H == 0) {
+        if (d_kept_off)
+            HIPCHK(ctx, hipMemsetAsync(d_kept_off, 0, 4, ctx->stream));
+        return MCX_OK;
+    }
+    const uint32_t nb = (H + SCAN_ITEMS - 1u) / SCAN_ITEMS;
+    /* scratch: name bits, per-host counts, block sums, offsets when the caller wants none, total */
+    const size_t o_cnt = up256(D ? D : 1), o_bsum = o_cnt + up256(4 * (size_t)H);
+    const size_t o_off = o_bsum + up256(4 * (size_t)nb), o_total = o_off + up256(4 * ((size_t)H + 1));
+    void *base;
+    int rc = mcx_scratch(ctx, o_total + 256, &base);
+    if (rc != MCX_OK)
+        return rc;
+    uint8_t *d_bits = (uint8_t *)base;
+    uint32_t *d_cnt = (uint32_t *)((char *)base + o_cnt), *d_bsum = (uint32_t *)((char *)base + o_bsum);
+    uint32_t *d_off = d_kept_off ? (uint32_t *)d_kept_off : (uint32_t *)((char *)base + o_off);
+    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
+    if (D)
+        dv_names<<<(D + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+            (const char *)d_drv_arena, (const uint32_t *)d_drv_off, D, d_bits);
+    if (N)
+        dv_classify<<<(N + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+            (const uint4 *)d_rec, N, d_bits, D, (uint8_t *)d_verdict);
+    const uint32_t host_blocks = (uint32_t)(((uint64_t)H * 64u + FL_THREADS - 1) / FL_THREADS);
+    dv_host<0><<<host_blocks, FL_THREADS, 0, ctx->stream>>>((const uint32_t *)d_dev_off, H, max_per_host,
+                                                           (uint8_t *)d_verdict, d_cnt, nullptr, nullptr, nullptr,
+                                                           nullptr);
+    mcx_scan_enqueue(ctx->stream, d_cnt, H, d_bsum, d_total, d_off);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
+    HIPCHK(ctx, hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (kept_total)
+        *kept_total = *h_total;
+    return MCX_OK;
+}
+
+int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, const void *d_s_off, uint32_t N,
+                          const void *d_dev_off, uint32_t H, const void *d_kept_off, uint32_t kept_total,
+                          void *d_S_out, void *d_s_off_out, void *d_src, uint64_t *bytes_out)
+{
+    if (!ctx || !d_s_off || !d_dev_off || !d_kept_off || !d_s_off_out || (N && !d_verdict) || kept_total > N)
+        return MCX_E_BAD_ARG;
+    if (bytes_out)
+        *bytes_out = 0;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    const uint32_t K = kept_total;
+    if (K == 0 || H == 0) {
+        HIPCHK(ctx, hipMemsetAsync(d_s_off_out, 0, 4, ctx->stream));
+        return MCX_OK;
+    }
+    const uint32_t nb = (K + SCAN_ITEMS - 1u) / SCAN_ITEMS;
+    const size_t o_len = up256(4 * (size_t)K), o_bsum = 2 * o_len, o_total = o_bsum + up256(4 * (size_t)nb);
+    void *base;
+    int rc = mcx_scratch(ctx, o_total + 256, &base);
+    if (rc != MCX_OK)
+        return rc;
+    uint32_t *src = d_src ? (uint32_t *)d_src : (uint32_t *)base;
+    uint32_t *len = (uint32_t *)((char *)base + o_len), *d_bsum = (uint32_t *)((char *)base + o_bsum);
+    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
+    const uint32_t host_blocks = (uint32_t)(((uint64_t)H * 64u + FL_THREADS - 1) / FL_THREADS);
+    dv_host<1><<<host_blocks, FL_THREADS, 0, ctx->stream>>>((const uint32_t *)d_dev_off, H, 0u,
+                                                           (uint8_t *)const_cast<void *>(d_verdict), nullptr,
+                                                           (const uint32_t *)d_kept_off, (const uint32_t *)d_s_off,
+                                                           src, len);
+    mcx_scan_enqueue(ctx->stream, len, K, d_bsum, d_total, (uint32_t *)d_s_off_out);
+    if (d_S_out && d_S) {
+        const uint64_t threads = (uint64_t)K * 16u;
+        dv_copy<<<(uint32_t)((threads + FL_THREADS - 1) / FL_THREADS), FL_THREADS, 0, ctx->stream>>>(
+            (const char *)d_S, (const uint32_t *)d_s_off, src, (const uint32_t *)d_s_off_out, K, (char *)d_S_out);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (bytes_out) {
+        unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
+        HIPCHK(ctx, hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *bytes_out = *h_total;
+    }
+    return MCX_OK;
+}
+
+int mcx_device_filter(mcx_ctx *ctx, const mcx_dev_rec_t *rec, uint32_t N, const char *drv_arena,
+                      const uint32_t *drv_off, uint32_t D, const uint32_t *dev_off, uint32_t H,
+                      uint32_t max_per_host, uint8_t *verdict, uint32_t *kept_off)
+{
+    if (!ctx || !dev_off || (N && (!rec || !verdict)) || (D && (!drv_off || (drv_off[D] && !drv_arena))))
+        return MCX_E_BAD_ARG;
+    if (dev_off[0] != 0 || dev_off[H] != N) {
+        ctx->err = "dev_off must run from 0 to N";
+        return MCX_E_BAD_ARG;
+    }
+    for (uint32_t h = 0; h < H; ++h)
+        if (dev_off[h + 1] < dev_off[h]) {
+            ctx->err = "dev_off not monotonic";
+            return MCX_E_BAD_ARG;
+        }
+    for (uint32_t d = 0; d < D; ++d)
+        if (drv_off[d + 1] < drv_off[d]) {
+            ctx->err = "drv_off not monotonic";
+            return MCX_E_BAD_ARG;
+        }
+    for (uint32_t i = 0; i < N; ++i)
+        if (rec[i].driver >= D && rec[i].driver < MCX_DRV_NOSLASH) {
+            ctx->err = "record " + std::to_string(i) + " names a driver outside the table";
+            return MCX_E_BAD_ARG;
+        }
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    const size_t nb_arena = D ? drv_off[D] : 0;
+    const size_t o_arena = up256(16 * (size_t)(N ? N : 1)), o_doff = o_arena + up256(nb_arena ? nb_arena : 1);
+    const size_t o_dev = o_doff + up256(4 * ((size_t)D + 1)), o_ver = o_dev + up256(4 * ((size_t)H + 1));
+    const size_t o_kept = o_ver + up256(N ? N : 1), bytes = o_kept + up256(4 * ((size_t)H + 1));
+    char *d = nullptr;
+    if (hipMalloc((void **)&d, bytes) != hipSuccess) {
+        ctx->err = "hipMalloc of the staging buffers failed";
+        return MCX_E_NOMEM;
+    }
+    hipError_t e = hipSuccess;
+    if (N)
+        e = hipMemcpyAsync(d, rec, 16 * (size_t)N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nb_arena)
+        e = hipMemcpyAsync(d + o_arena, drv_arena, nb_arena, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && D)
+        e = hipMemcpyAsync(d + o_doff, drv_off, 4 * ((size_t)D + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d + o_dev, dev_off, 4 * ((size_t)H + 1), hipMemcpyHostToDevice, ctx->stream);
+    int rc = MCX_OK;
+    if (e != hipSuccess) {
+        ctx->err = std::string("copy in: ") + hipGetErrorString(e);
+        rc = MCX_E_HIP;
+    }
+    uint64_t total = 0;
+    if (rc == MCX_OK)
+        rc = mcx_device_filter_dev(ctx, d, N, d + o_arena, d + o_doff, D, d + o_dev, H, max_per_host, d + o_ver,
+                                   d + o_kept, &total);
+    if (rc == MCX_OK) {
+        if (N)
+            e = hipMemcpyAsync(verdict, d + o_ver, N, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && kept_off)
+            e = hipMemcpyAsync(kept_off, d + o_kept, 4 * ((size_t)H + 1), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->err = std::string("copy back: ") + hipGetErrorString(e);
+            rc = MCX_E_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+} /* extern "C" */

@@ -18,8 +18,8 @@
 #include <string.h>
 
 #include "mcx_internal.h"
+#include "mcx_scan.h"
 
-#define FL_THREADS 256
 
 /* largest h with off[h] <= i, for off[0] = 0 <= i < off[H] */
 __device__ __forceinline__ uint32_t fl_owner(const uint32_t *__restrict__ off, uint32_t H, uint32_t i)
@@ -179,117 +179,9 @@ fl_columns(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, 
     }
 }
 
-/* ---- exclusive scan of H counts into H + 1 offsets ------------------------ */
-/* three small kernels: per-block sums, one block over the sums, per-block scan */
-
-#define SCAN_ITEMS 1024u /* per block: 256 threads x 4 */
-
-__device__ __forceinline__ uint32_t fl_block_exclusive(uint32_t mine, uint32_t *total_out)
-{
-    __shared__ uint32_t wsum[FL_THREADS / 64];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = mine;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d)
-            incl += o;
-    }
-    __syncthreads(); /* wsum may still be read by a previous call */
-    if (lane == 63u)
-        wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < FL_THREADS / 64; ++k) {
-        if (k < wave)
-            base += wsum[k];
-        total += wsum[k];
-    }
-    *total_out = total;
-    return base + incl - mine;
-}
-
-__global__ void __launch_bounds__(FL_THREADS)
-fl_scan_sums(const uint32_t *__restrict__ cnt, uint32_t H, uint32_t *__restrict__ bsum)
-{
-    const uint32_t i0 = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4u;
-    uint32_t mine = 0;
-    for (uint32_t k = 0; k < 4u; ++k)
-        if (i0 + k < H)
-            mine += cnt[i0 + k];
-    uint32_t total;
-    (void)fl_block_exclusive(mine, &total);
-    if (threadIdx.x == 0)
-        bsum[blockIdx.x] = total;
-}
-
-/* single block: bsum[b] becomes the sum of the blocks before b; 64-bit grand total */
-__global__ void __launch_bounds__(FL_THREADS)
-fl_scan_top(uint32_t *bsum, uint32_t nb, unsigned long long *grand)
-{
-    unsigned long long carry = 0;
-    for (uint32_t b0 = 0; b0 < nb; b0 += FL_THREADS) {
-        const uint32_t b = b0 + threadIdx.x;
-        const uint32_t mine = b < nb ? bsum[b] : 0u;
-        uint32_t total;
-        const uint32_t ex = fl_block_exclusive(mine, &total);
-        if (b < nb)
-            bsum[b] = (uint32_t)carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0)
-        *grand = carry;
-}
-
-__global__ void __launch_bounds__(FL_THREADS)
-fl_scan_apply(const uint32_t *__restrict__ cnt, uint32_t H, const uint32_t *__restrict__ bsum,
-              uint32_t *__restrict__ off)
-{
-    const uint32_t i0 = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4u;
-    uint32_t c[4], mine = 0;
-    for (uint32_t k = 0; k < 4u; ++k) {
-        c[k] = i0 + k < H ? cnt[i0 + k] : 0u;
-        mine += c[k];
-    }
-    uint32_t total;
-    uint32_t at = bsum[blockIdx.x] + fl_block_exclusive(mine, &total);
-    for (uint32_t k = 0; k < 4u; ++k) {
-        if (i0 + k < H)
-            off[i0 + k] = at;
-        at += c[k];
-    }
-    /* off[H]: the thread that owns the last count also writes the end */
-    if (H - 1u >= i0 && H - 1u < i0 + 4u)
-        off[H] = at;
-}
-
 /* ------------------------------------------------------------------------- */
 /* C ABI                                                                      */
 /* ------------------------------------------------------------------------- */
-
-static int fleet_scratch(mcx_ctx *ctx, size_t bytes, void **out)
-{
-    if (ctx->fleet_bytes < bytes) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_fleet);
-        ctx->d_fleet = nullptr;
-        ctx->fleet_bytes = 0;
-        if (hipMalloc(&ctx->d_fleet, bytes) != hipSuccess) {
-            ctx->err = "fleet scratch of " + std::to_string(bytes) +
-                       " bytes does not fit the device: split the fleet into groups of hosts";
-            return MCX_E_NOMEM;
-        }
-        ctx->fleet_bytes = bytes;
-    }
-    *out = ctx->d_fleet;
-    return MCX_OK;
-}
-
-static size_t up256(size_t x)
-{
-    return (x + 255) & ~(size_t)255;
-}
 
 extern "C" {
 
@@ -325,7 +217,7 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
     const size_t o_cnt = o_count + up256(4 * (size_t)(N ? N : 1)), o_bsum = o_cnt + up256(4 * (size_t)H);
     const size_t o_hw = o_bsum + up256(4 * (size_t)nb), o_total = o_hw + up256(V ? V : 1);
     void *base;
-    int rc = fleet_scratch(ctx, o_total + 256, &base);
+    int rc = mcx_scratch(ctx, o_total + 256, &base);
     if (rc != MCX_OK)
         return rc;
     uint32_t *U = (uint32_t *)base, *L = (uint32_t *)((char *)base + mat);

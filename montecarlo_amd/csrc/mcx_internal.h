@@ -90,6 +90,31 @@ static inline int mcx_set_device(mcx_ctx *ctx)
     return 0;
 }
 
+/* the context's scratch for fleet-sized work, grown on demand (the stream is
+ * drained before the old block is freed), freed with the context */
+static inline int mcx_scratch(mcx_ctx *ctx, size_t bytes, void **out)
+{
+    if (ctx->fleet_bytes < bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_fleet);
+        ctx->d_fleet = nullptr;
+        ctx->fleet_bytes = 0;
+        if (hipMalloc(&ctx->d_fleet, bytes) != hipSuccess) {
+            ctx->err = "fleet scratch of " + std::to_string(bytes) +
+                       " bytes does not fit the device: split the fleet into groups of hosts";
+            return MCX_E_NOMEM;
+        }
+        ctx->fleet_bytes = bytes;
+    }
+    *out = ctx->d_fleet;
+    return MCX_OK;
+}
+
+static inline size_t up256(size_t x)
+{
+    return (x + 255) & ~(size_t)255;
+}
+
 template <class T>
 static int mcx_dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 {

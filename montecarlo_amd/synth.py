@@ -134,3 +134,88 @@ def fleet_hosts(seed, V, H, mean_dev=100, max_extra=8, h0=0, h1=None):
     extra_off = np.zeros(n + 1, dtype=np.uint32)
     extra_off[1:] = np.cumsum(extra_cnt[:n], dtype=np.uint64).astype(np.uint32)
     return dev_cnt[:n], extra_off, ids[:X]
+
+
+# ---- fleet inventory records ----------------------------------------------------
+
+DRIVER_NAMES = [
+    # the 8 names the reference drops PCI devices for, host controllers, hubs
+    "pcieport", "pci_bridge", "pciehp", "pcie_aspm", "pcie_pme", "pcie_edr", "shpchp", "piix4_smbus",
+    "xhci_hcd", "ehci-pci", "ehci_hcd", "ohci_hcd", "uhci_hcd", "xhci-pci-renesas", "hub", "dwc2_hcd_x",
+    # near misses
+    "pcieport2", "pcie", "hubs", "hcX", "shpchp_", "hc", "Hub",
+    # ordinary drivers
+    "e1000e", "igb", "ixgbe", "nvme", "ahci", "virtio-pci", "amdgpu", "i915", "snd_hda_intel", "iwlwifi", "r8169",
+    "usbhid", "usb-storage", "uas", "btusb", "cdc_acm", "r8152", "uvcvideo", "snd-usb-audio", "hid-generic", "sd",
+    "sr", "mpt3sas", "megaraid_sas", "pcmcia_x", "serial_cs",
+]
+
+
+def driver_names_packed():
+    from .binding import pack_strings
+    return pack_strings([n.encode() for n in DRIVER_NAMES])
+
+
+def device_records(seed, S, s_off):
+    """One packed record (binding.DEV_REC) per modalias string: the subsystem
+    follows the string's bus tag, everything else is drawn so that every test of
+    the reference's device list fires on a few per cent of the devices."""
+    from . import binding as b
+    rng = np.random.default_rng(seed)
+    s_off = np.asarray(s_off, dtype=np.int64)
+    N = len(s_off) - 1
+    rec = np.zeros(N, dtype=b.DEV_REC)
+    if N == 0:
+        return rec
+    S = np.asarray(S, dtype=np.uint8)
+    first = S[np.minimum(s_off[:-1], max(len(S) - 1, 0))]
+    r = rng.random(N)
+    sub = np.full(N, b.SUB_OTHER, dtype=np.uint8)
+    sub[first == ord("p")] = b.SUB_PCI            # pci: (and platform:, told apart below)
+    second = S[np.minimum(s_off[:-1] + 1, max(len(S) - 1, 0))]
+    sub[(first == ord("p")) & (second != ord("c"))] = b.SUB_OTHER
+    sub[first == ord("u")] = b.SUB_USB
+    sub[first == ord("h")] = b.SUB_HID
+    other = sub == b.SUB_OTHER
+    sub[other & (r < 0.35)] = b.SUB_SCSI
+    sub[other & (r >= 0.35) & (r < 0.45)] = b.SUB_PCMCIA
+    rec["subsystem"] = sub
+    D = len(DRIVER_NAMES)
+    drv = rng.integers(23, D, size=N).astype(np.uint32)          # ordinary drivers
+    special = rng.random(N)
+    drv[special < 0.10] = rng.integers(0, 23, size=int((special < 0.10).sum()))   # infra, hcd, hub, near misses
+    drv[(special >= 0.10) & (special < 0.30)] = b.DRV_NONE
+    drv[(special >= 0.30) & (special < 0.31)] = b.DRV_NOSLASH
+    rec["driver"] = drv
+    # pci: class codes, a tenth of them infrastructure classes
+    cls = rng.integers(0, 1 << 24, size=N).astype(np.uint32)
+    pick = rng.random(N)
+    cls[pick < 0.04] = 0x060400 | (cls[pick < 0.04] & 0xFF)
+    cls[(pick >= 0.04) & (pick < 0.07)] = 0x0C0500
+    cls[(pick >= 0.07) & (pick < 0.10)] = 0x088000
+    cls[(pick >= 0.10) & (pick < 0.12)] = 0x0C0330          # usb controller: base 0x0c but not SMBus
+    cls[(pick >= 0.12) & (pick < 0.60)] = 0x020000
+    rec["pci_class"] = cls
+    attrs = np.zeros(N, dtype=np.uint8)
+    a = rng.random((7, N))
+    is_usb, is_pci, is_scsi = sub == b.SUB_USB, sub == b.SUB_PCI, sub == b.SUB_SCSI
+    attrs[is_pci & (a[0] < 0.95)] |= b.DA_PCI_CLASS
+    attrs[is_usb & (a[1] < 0.93)] |= b.DA_IFACE_CLASS
+    attrs[is_usb & (a[2] < 0.95)] |= b.DA_PARENT
+    attrs[is_usb & (a[3] < 0.93)] |= b.DA_PARENT_CLASS
+    attrs[is_usb & (a[4] < 0.20)] |= b.DA_OWN_CLASS
+    attrs[is_scsi & (a[5] < 0.80)] |= b.DA_SCSI_MODEL
+    attrs[is_scsi & (a[6] < 0.80)] |= b.DA_SCSI_VENDOR
+    attrs[~(is_usb | is_pci | is_scsi) & (a[0] < 0.1)] |= np.uint8(rng.integers(1, 128))
+    rec["attrs"] = attrs
+    classes = np.array([0x00, 0x01, 0x02, 0x03, 0x08, 0x09, 0x0A, 0x0E, 0xE0, 0xFF, 0x90, 0x80], dtype=np.uint8)
+    rec["iface_class"] = classes[rng.integers(0, len(classes), size=N)]
+    rec["parent_class"] = classes[rng.integers(0, len(classes), size=N)]
+    rec["own_class"] = classes[rng.integers(0, len(classes), size=N)]
+    dt = np.zeros(N, dtype=np.uint8)
+    u = rng.random(N)
+    dt[is_usb] = np.where(u[is_usb] < 0.85, b.DT_USB_INTERFACE, np.where(u[is_usb] < 0.95, b.DT_USB_DEVICE, b.DT_NONE))
+    dt[is_scsi] = rng.integers(0, 7, size=int(is_scsi.sum()))
+    dt[~(is_usb | is_scsi)] = rng.integers(0, 7, size=int((~(is_usb | is_scsi)).sum()))
+    rec["devtype"] = dt
+    return rec

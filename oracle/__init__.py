@@ -47,6 +47,8 @@ def oracle():
         lib.orc_has_hw_alias.argtypes = [ctypes.c_char_p]
         lib.orc_fleet_roots.restype = u64
         lib.orc_fleet_roots.argtypes = [_vp, _vp, u32, _vp, _vp, u32, _vp, _vp, _vp, _vp, _vp, _vp]
+        lib.orc_device_filter.restype = None
+        lib.orc_device_filter.argtypes = [_vp, u32, _vp, _vp, u32, _vp, u32, u32, _vp, _vp]
         _ORC = lib
     return _ORC
 
@@ -140,6 +142,21 @@ def fleet_roots(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe_nam
     ids = np.zeros(max(total, 1), dtype=np.uint32)
     oracle().orc_fleet_roots(*args, _p(ids))
     return root_off, ids[:total]
+
+
+def device_filter(rec, drv_arena, drv_off, dev_off, max_per_host=0):
+    """(verdict & 3, kept_off) of the per-host device list over packed records
+    (rec: structured or raw array of 16-byte records)"""
+    rec = np.ascontiguousarray(rec)
+    assert rec.itemsize == 16
+    drv_off = np.ascontiguousarray(drv_off, dtype=np.uint32)
+    dev_off = np.ascontiguousarray(dev_off, dtype=np.uint32)
+    N, H = len(rec), len(dev_off) - 1
+    verdict = np.zeros(max(N, 1), dtype=np.uint8)
+    kept_off = np.zeros(H + 1, dtype=np.uint32)
+    oracle().orc_device_filter(_p(rec), N, _p(_c(drv_arena, np.uint8)), _p(drv_off), len(drv_off) - 1, _p(dev_off),
+                               H, int(max_per_host), _p(verdict), _p(kept_off))
+    return verdict[:N], kept_off
 
 
 class TwinTable:

@@ -29,6 +29,7 @@
 #include <fnmatch.h>
 #include <locale.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -448,4 +449,166 @@ uint64_t orc_fleet_roots(const uint32_t *rowptr, const uint32_t *col, uint32_t V
     free(held);
     free(list);
     return total;
+}
+
+/* ---- fleet inventory: the device list of each host ------------------------ */
+
+/*
+ * A packed device record (the layout of include/mcx.h, restated here so that
+ * the oracle depends on nothing of the product).  The oracle turns a record
+ * back into the strings a sysfs node would hold and then runs the reference's
+ * tests on those strings the way the reference does: sscanf("0x%x") and the
+ * class masks of mc_is_infrastructure_device (reference
+ * montecarlo/libmontecarlo.c:748-762), strcmp against the 8 driver names
+ * (778-785), the SCSI devtype tests (790-818), and in mc_list_all_devices the
+ * usb_interface / hub / parent tests (291-321), strstr "hcd" / strcmp "hub"
+ * (412-413) and the `count >= max` stop (259-260); mc_is_excluded_device's
+ * three "08" tests (841-869).
+ */
+typedef struct {
+    uint8_t subsystem, devtype, attrs, iface_class;
+    uint32_t pci_class;
+    uint8_t parent_class, own_class;
+    uint16_t reserved;
+    uint32_t driver;
+} orc_dev_rec;
+
+static const char *orc_subsystem_name(uint8_t s)
+{
+    static const char *names[] = {"usb", "pci", "hid", "scsi", "pcmcia"};
+    return s < 5 ? names[s] : "other";
+}
+
+static const char *orc_devtype_name(uint8_t t)
+{
+    static const char *names[] = {NULL, "usb_device", "usb_interface", "scsi_host", "scsi_target", "scsi_generic",
+                                  "scsi_device"};
+    return t < 7 ? names[t] : "other";
+}
+
+/* mc_is_infrastructure_device over the strings of one node; driver_target is
+ * the link target of <syspath>/driver or NULL */
+static int orc_is_infrastructure(const char *subsystem, const char *class_str, const char *driver_target,
+                                 const char *devtype, const char *model, const char *vendor)
+{
+    if (strcmp(subsystem, "pci") == 0) {
+        if (class_str) {
+            unsigned int class_code = 0;
+            sscanf(class_str, "0x%x", &class_code);
+            unsigned int base_class = (class_code >> 16) & 0xFF, sub_class = (class_code >> 8) & 0xFF;
+            if (base_class == 0x06 || (base_class == 0x0c && sub_class == 0x05) || base_class == 0x08)
+                return 1;
+        }
+        if (driver_target) {
+            const char *name = strrchr(driver_target, '/');
+            if (!name)
+                return 1;
+            ++name;
+            static const char *infra[] = {"pcieport", "pci_bridge", "pciehp",  "pcie_aspm", "pcie_pme",
+                                          "pcie_edr", "shpchp",     "piix4_smbus", NULL};
+            for (int i = 0; infra[i]; ++i)
+                if (strcmp(name, infra[i]) == 0)
+                    return 1;
+        }
+    }
+    if (strcmp(subsystem, "scsi") == 0) {
+        if (!devtype)
+            return 1;
+        if (strcmp(devtype, "scsi_host") == 0 || strcmp(devtype, "scsi_target") == 0 ||
+            strcmp(devtype, "scsi_generic") == 0)
+            return 1;
+        if (!model && !vendor)
+            return 1;
+    }
+    return 0;
+}
+
+/*
+ * verdict[i]: bit 0 = listed, bit 1 = excluded (mass storage); kept_off[h+1] -
+ * kept_off[h] = listed devices of host h.  max_per_host 0 = no limit.
+ * Driver d of the table is the string drv_arena[drv_off[d] .. drv_off[d+1]);
+ * 0xFFFFFFFF = no link, 0xFFFFFFFE = a link target without '/'.
+ */
+void orc_device_filter(const orc_dev_rec *rec, uint32_t N, const char *drv_arena, const uint32_t *drv_off,
+                       uint32_t D, const uint32_t *dev_off, uint32_t H, uint32_t max_per_host, uint8_t *verdict,
+                       uint32_t *kept_off)
+{
+    (void)N;
+    kept_off[0] = 0;
+    for (uint32_t h = 0; h < H; ++h) {
+        uint32_t count = 0;
+        for (uint32_t i = dev_off[h]; i < dev_off[h + 1]; ++i) {
+            const orc_dev_rec *r = &rec[i];
+            char class_buf[16], ic[4], pc[4], oc[4], target[160];
+            const char *subsystem = orc_subsystem_name(r->subsystem);
+            const char *devtype = orc_devtype_name(r->devtype);
+            const char *class_str = NULL, *iface = NULL, *pclass = NULL, *oclass = NULL, *driver_target = NULL;
+            if (r->attrs & 0x01) {
+                snprintf(class_buf, sizeof class_buf, "0x%06x", r->pci_class & 0xFFFFFFu);
+                class_str = class_buf;
+            }
+            if (r->attrs & 0x02) {
+                snprintf(ic, sizeof ic, "%02x", r->iface_class);
+                iface = ic;
+            }
+            const int has_parent = (r->attrs & 0x04) != 0;
+            if (has_parent && (r->attrs & 0x08)) {
+                snprintf(pc, sizeof pc, "%02x", r->parent_class);
+                pclass = pc;
+            }
+            if (r->attrs & 0x10) {
+                snprintf(oc, sizeof oc, "%02x", r->own_class);
+                oclass = oc;
+            }
+            const char *model = (r->attrs & 0x20) ? "model" : NULL, *vendor = (r->attrs & 0x40) ? "vendor" : NULL;
+            if (r->driver == 0xFFFFFFFEu) {
+                driver_target = "dangling";
+            } else if (r->driver != 0xFFFFFFFFu && r->driver < D) {
+                uint32_t n = drv_off[r->driver + 1] - drv_off[r->driver];
+                if (n > 100)
+                    n = 100;
+                snprintf(target, sizeof target, "../../../bus/%s/drivers/%.*s", subsystem, (int)n,
+                         drv_arena + drv_off[r->driver]);
+                driver_target = target;
+            }
+
+            uint8_t v = 0;
+            /* mc_is_excluded_device */
+            if ((oclass && strcmp(oclass, "08") == 0) || (iface && strcmp(iface, "08") == 0) ||
+                (pclass && strcmp(pclass, "08") == 0))
+                v |= 2;
+
+            /* mc_list_all_devices */
+            int listed = 1;
+            if (count >= max_per_host && max_per_host)
+                listed = 0;
+            else if (orc_is_infrastructure(subsystem, class_str, driver_target, devtype, model, vendor))
+                listed = 0;
+            else if (strcmp(subsystem, "usb") == 0) {
+                if (!devtype || strcmp(devtype, "usb_interface") != 0)
+                    listed = 0;
+                else if (iface && strcmp(iface, "09") == 0)
+                    listed = 0;
+                else if (!has_parent)
+                    listed = 0;
+                else if (pclass && strcmp(pclass, "09") == 0)
+                    listed = 0;
+            } else if (strcmp(subsystem, "pci") != 0 && strcmp(subsystem, "hid") != 0 &&
+                       strcmp(subsystem, "scsi") != 0 && strcmp(subsystem, "pcmcia") != 0)
+                listed = 0;
+            if (listed && driver_target) {
+                const char *dname = strrchr(driver_target, '/');
+                const char *final_driver = dname ? dname + 1 : "unknown";
+                if (strcmp(subsystem, "usb") == 0 &&
+                    (strstr(final_driver, "hcd") != NULL || strcmp(final_driver, "hub") == 0))
+                    listed = 0;
+            }
+            if (listed) {
+                v |= 1;
+                ++count;
+            }
+            verdict[i] = v;
+        }
+        kept_off[h + 1] = kept_off[h] + count;
+    }
 }

@@ -1,0 +1,127 @@
+"""GPU parity of the device-list predicates and the string packing
+(mcx_device_filter, mcx_device_filter_dev, mcx_fleet_compact_dev through the C
+ABI) against the CPU oracle on the same seeded records.  Bit-exact."""
+import numpy as np
+import pytest
+
+from montecarlo_amd import McxError, synth
+from montecarlo_amd import binding as b
+from montecarlo_amd.binding import pack_strings
+
+from test_devfilter_cpu import DRV, HAND, hand_records
+
+pytestmark = pytest.mark.gpu
+
+
+def host_offsets(rng, N, H):
+    """H hosts over N devices, some of them empty, one of them large"""
+    cuts = np.sort(rng.integers(0, N + 1, size=H - 1))
+    if H >= 10:
+        cuts[: H // 10] = cuts[H // 10]      # a run of empty hosts
+    return np.concatenate([[0], np.sort(cuts), [N]]).astype(np.uint32)
+
+
+def test_hand_table_with_reasons(gpu_ctx):
+    rec, want = hand_records()
+    arena, off = pack_strings([d.encode() for d in DRV])
+    v, kept = gpu_ctx.device_filter(rec, arena, off, np.array([0, len(rec)], np.uint32))
+    assert (v & 3).tolist() == want.tolist()
+    assert kept.tolist() == [0, int((want & 1).sum())]
+    reasons = (v >> 4).tolist()
+    assert all((r == 0) == bool(w & 1) for r, w in zip(reasons, want))
+    # PCI rows of the table, in order: why each dropped one was dropped
+    assert reasons[:10] == [0, 2, 2, 0, 2, 0, 3, 3, 3, 0]
+    assert reasons[10:26] == [0, 5, 5, 6, 6, 5, 0, 7, 7, 0, 0, 0, 0, 0, 5, 5]
+    assert reasons[26:34] == [0, 0, 4, 4, 4, 4, 4, 0]
+    assert reasons[34:] == [0, 0, 0, 1, 1]
+
+
+@pytest.mark.parametrize("seed,N,H,cap", [(1, 50000, 700, 0), (2, 50000, 700, 64), (3, 3000, 1, 0), (4, 3000, 3000, 1),
+                                           (5, 70000, 10, 64), (6, 100, 400, 2)])
+def test_filter_vs_oracle(gpu_ctx, oracle_mod, seed, N, H, cap):
+    rng = np.random.default_rng(seed)
+    S, s_off = synth.modalias_strings(seed, 2000, N)
+    rec = synth.device_records(seed, S, s_off)
+    arena, off = synth.driver_names_packed()
+    dev_off = host_offsets(rng, N, H)
+    v, kept = gpu_ctx.device_filter(rec, arena, off, dev_off, cap)
+    o_v, o_kept = oracle_mod.device_filter(rec, arena, off, dev_off, cap)
+    assert np.array_equal(v & 3, o_v)
+    assert np.array_equal(kept, o_kept)
+    assert np.array_equal((v >> 4) == 0, (v & 1) == 1)
+    if cap:
+        assert (np.diff(kept.astype(np.int64)) <= cap).all() and ((v >> 4) == 8).any()
+
+
+def test_compact_and_match(gpu_ctx, oracle_mod):
+    """listed strings packed on the device, then matched: the same answers as
+    matching everything and dropping the unlisted devices afterwards"""
+    seed, N, H, P = 11, 40000, 900, 3000
+    rng = np.random.default_rng(seed)
+    A, a_off, a_mod = synth.alias_table(seed, P)
+    S, s_off = synth.modalias_strings(seed + 1, P, N)
+    rec = synth.device_records(seed, S, s_off)
+    arena, off = synth.driver_names_packed()
+    dev_off = host_offsets(rng, N, H)
+    ctx = gpu_ctx
+    ctx.alias_table_load(A, a_off, a_mod)
+    d_rec, d_arena, d_off = ctx.to_device(rec), ctx.to_device(arena), ctx.to_device(off)
+    d_dev, d_S, d_soff = ctx.to_device(dev_off), ctx.to_device(S), ctx.to_device(s_off)
+    d_v, d_kept = ctx.alloc(N), ctx.alloc(4 * (H + 1))
+    K = ctx.device_filter_dev(d_rec.ptr, N, d_arena.ptr, d_off.ptr, len(off) - 1, d_dev.ptr, H, 64, d_v.ptr, d_kept.ptr)
+    o_v, o_kept = oracle_mod.device_filter(rec, arena, off, dev_off, 64)
+    assert K == o_kept[-1] and np.array_equal(d_v.download(np.uint8, N) & 3, o_v)
+    d_S2, d_soff2, d_src = ctx.alloc(len(S)), ctx.alloc(4 * (K + 1)), ctx.alloc(4 * K)
+    nbytes = ctx.fleet_compact_dev(d_v.ptr, d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_kept.ptr, K, d_S2.ptr,
+                                   d_soff2.ptr, d_src.ptr)
+    keep = np.nonzero(o_v & 1)[0]
+    lens = np.diff(s_off.astype(np.int64))[keep]
+    want_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    raw = S.tobytes()
+    want_S = np.frombuffer(b"".join(raw[s_off[i]:s_off[i + 1]] for i in keep), dtype=np.uint8)
+    assert nbytes == len(want_S)
+    assert np.array_equal(d_src.download(np.uint32, K), keep.astype(np.uint32))
+    assert np.array_equal(d_soff2.download(np.uint32, K + 1), want_off)
+    assert np.array_equal(d_S2.download(np.uint8, len(S))[:nbytes], want_S)
+    # without the optional index array, and without waiting for the byte count
+    d_S3, d_soff3 = ctx.alloc(len(S)), ctx.alloc(4 * (K + 1))
+    assert ctx.fleet_compact_dev(d_v.ptr, d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_kept.ptr, K, d_S3.ptr,
+                                 d_soff3.ptr, None, want_bytes=False) is None
+    assert np.array_equal(d_S3.download(np.uint8, len(S))[:nbytes], want_S)
+    assert np.array_equal(d_soff3.download(np.uint32, K + 1), want_off)
+    # the packed batch through the alias match
+    d_f, d_c = ctx.alloc(4 * K), ctx.alloc(4 * K)
+    ctx.alias_match_dev(d_S2.ptr, d_soff2.ptr, K, d_f.ptr, d_c.ptr)
+    first, count = ctx.alias_match(S, s_off)
+    assert np.array_equal(d_f.download(np.uint32, K), first[keep])
+    assert np.array_equal(d_c.download(np.uint32, K), count[keep])
+    for buf in (d_rec, d_arena, d_off, d_dev, d_S, d_soff, d_v, d_kept, d_S2, d_soff2, d_src, d_S3, d_soff3, d_f, d_c):
+        buf.free()
+
+
+def test_edge_cases(gpu_ctx):
+    arena, off = pack_strings([d.encode() for d in DRV])
+    empty = np.zeros(0, dtype=b.DEV_REC)
+    v, kept = gpu_ctx.device_filter(empty, arena, off, np.zeros(1, np.uint32))
+    assert len(v) == 0 and kept.tolist() == [0]
+    v, kept = gpu_ctx.device_filter(empty, arena, off, np.zeros(5, np.uint32), 3)
+    assert kept.tolist() == [0] * 5
+    rec, want = hand_records()
+    # no driver table at all: names cannot match, links still count
+    no_names = rec.copy()
+    no_names["driver"][no_names["driver"] < b.DRV_NOSLASH] = b.DRV_NONE
+    v, _ = gpu_ctx.device_filter(no_names, np.zeros(0, np.uint8), np.zeros(1, np.uint32),
+                                 np.array([0, len(rec)], np.uint32))
+    assert (v[0] & 1) == 1 and (v[6] & 1) == 1 and (v[8] & 1) == 0
+    with pytest.raises(McxError) as e:
+        gpu_ctx.device_filter(rec, arena, off, np.array([0, 3], np.uint32))       # dev_off does not end at N
+    assert e.value.rc == -2
+    bad = rec.copy()
+    bad["driver"][4] = len(DRV)
+    with pytest.raises(McxError) as e:
+        gpu_ctx.device_filter(bad, arena, off, np.array([0, len(rec)], np.uint32))
+    assert e.value.rc == -2
+    d = gpu_ctx.alloc(64)
+    with pytest.raises(McxError):
+        gpu_ctx.device_filter_dev(d.ptr + 4, 1, None, None, 0, d.ptr, 1, 0, d.ptr, None)   # misaligned records
+    d.free()
