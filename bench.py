@@ -370,9 +370,41 @@ def bench_fleet(ctx, synth, args):
     ctx.timer_begin()
     ctx.alias_match_dev(d_S.ptr, d_soff.ptr, N, d_f.ptr, d_c.ptr)
     k1_ms = ctx.timer_end()
-    for b in bufs + [d_roff, d_rid, d_f, d_c]:
+    for b in bufs[3:] + [d_roff, d_rid, d_f, d_c]:
+        b.free()
+    # the step before the match: which devices a host's list would show (per-host limit 64,
+    # the value the reference's UI passes), and the packing of their strings
+    rec = synth.device_records(seed + 5, S, s_off)
+    arena, off = synth.driver_names_packed()
+    d_rec, d_arena, d_off = ctx.to_device(rec), ctx.to_device(arena), ctx.to_device(off)
+    d_v, d_kept = ctx.alloc(N), ctx.alloc(4 * (H + 1))
+    D = len(off) - 1
+    K = ctx.device_filter_dev(d_rec.ptr, N, d_arena.ptr, d_off.ptr, D, d_dev.ptr, H, 64, d_v.ptr, d_kept.ptr)
+    d_S2, d_soff2 = ctx.alloc(len(S)), ctx.alloc(4 * (K + 1))
+    kept_bytes = ctx.fleet_compact_dev(d_v.ptr, d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_kept.ptr, K, d_S2.ptr,
+                                       d_soff2.ptr)
+    ctx.timer_begin()
+    for _ in range(reps):
+        ctx.device_filter_dev(d_rec.ptr, N, d_arena.ptr, d_off.ptr, D, d_dev.ptr, H, 64, d_v.ptr, d_kept.ptr)
+    filter_ms = ctx.timer_end() / reps
+    ctx.timer_begin()
+    for _ in range(reps):
+        ctx.fleet_compact_dev(d_v.ptr, d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_kept.ptr, K, d_S2.ptr, d_soff2.ptr,
+                              None, want_bytes=False)
+    compact_ms = ctx.timer_end() / reps
+    filter_bytes = 16 * N + 2 * N + 8 * (H + 1)
+    compact_bytes = N + 4 * (N + 1) + 8 * (H + 1) + 2 * kept_bytes + 4 * (K + 1)
+    for b in bufs[:3] + [d_rec, d_arena, d_off, d_v, d_kept, d_S2, d_soff2]:
         b.free()
     return {
+        "device_filter": {
+            "listed_devices": K,
+            "filter_ms": filter_ms,
+            "filter_GBps": filter_bytes / (filter_ms / 1e3) / 1e9,
+            "compact_ms": compact_ms,
+            "compact_GBps": compact_bytes / (compact_ms / 1e3) / 1e9,
+            "bytes": {"filter": int(filter_bytes), "compact": int(compact_bytes)},
+        },
         "workload": f"configs[4]: {H} hosts, {N} devices, {P} alias patterns, {V} modules, {len(col)} edges, "
                     f"{X} extra loaded modules, seed {seed}",
         "ms_per_pass": ms,

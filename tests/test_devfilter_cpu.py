@@ -2,6 +2,8 @@
 worked out by hand from the reference's tests on one sysfs node
 (montecarlo/libmontecarlo.c:233-440, 729-874).  The reference holds no fixtures
 for these functions, so the hand table below is what pins the oracle."""
+import os
+
 import numpy as np
 
 import oracle
@@ -106,3 +108,93 @@ def test_synthetic_records_cover_every_branch():
         m = rec["subsystem"] == sub
         assert (v[m] & 1).any() and not (v[m] & 1).all()
     assert (v[rec["subsystem"] == b.SUB_HID] & 1).all() and not (v[rec["subsystem"] == b.SUB_OTHER] & 1).any()
+
+
+def records_from_tree(root):
+    """What an inventory agent would pack for every node of the five
+    subsystems of a sysfs tree: one record per device, the driver names found"""
+    subs = {"usb": b.SUB_USB, "pci": b.SUB_PCI, "hid": b.SUB_HID, "scsi": b.SUB_SCSI, "pcmcia": b.SUB_PCMCIA}
+    devtypes = {"usb_device": b.DT_USB_DEVICE, "usb_interface": b.DT_USB_INTERFACE, "scsi_host": b.DT_SCSI_HOST,
+                "scsi_target": b.DT_SCSI_TARGET, "scsi_generic": b.DT_SCSI_GENERIC}
+
+    def attr(d, name):
+        try:
+            with open(os.path.join(d, name)) as f:
+                return f.readline().rstrip("\n")
+        except OSError:
+            return None
+
+    def devtype_of(d):
+        for line in open(os.path.join(d, "uevent")):
+            if line.startswith("DEVTYPE="):
+                return line[8:].strip()
+        return None
+
+    paths, recs, drivers = [], [], []
+    for sub, code in subs.items():
+        bd = os.path.join(root, "sys", "bus", sub, "devices")
+        if not os.path.isdir(bd):
+            continue
+        for name in sorted(os.listdir(bd)):
+            d = os.path.realpath(os.path.join(bd, name))
+            attrs, f = 0, dict(iface=0, pci=0, parent=0, own=0)
+            dt = devtype_of(d)
+            devtype = b.DT_NONE if dt is None else devtypes.get(dt, b.DT_OTHER)
+            if attr(d, "class") is not None:
+                attrs |= b.DA_PCI_CLASS
+                f["pci"] = int(attr(d, "class"), 16)
+            if attr(d, "bInterfaceClass") is not None:
+                attrs |= b.DA_IFACE_CLASS
+                f["iface"] = int(attr(d, "bInterfaceClass"), 16)
+            if attr(d, "bDeviceClass") is not None:
+                attrs |= b.DA_OWN_CLASS
+                f["own"] = int(attr(d, "bDeviceClass"), 16)
+            up = os.path.dirname(d)
+            while up.startswith(os.path.join(root, "sys", "devices")):       # nearest usb_device above
+                if os.path.exists(os.path.join(up, "uevent")) and devtype_of(up) == "usb_device" and \
+                        os.path.basename(os.path.realpath(os.path.join(up, "subsystem"))) == "usb":
+                    attrs |= b.DA_PARENT
+                    if attr(up, "bDeviceClass") is not None:
+                        attrs |= b.DA_PARENT_CLASS
+                        f["parent"] = int(attr(up, "bDeviceClass"), 16)
+                    break
+                up = os.path.dirname(up)
+            if attr(d, "model") is not None:
+                attrs |= b.DA_SCSI_MODEL
+            if attr(d, "vendor") is not None and code == b.SUB_SCSI:
+                attrs |= b.DA_SCSI_VENDOR
+            drv = b.DRV_NONE
+            link = os.path.join(d, "driver")
+            if os.path.islink(link):
+                dn = os.path.basename(os.readlink(link))
+                if dn not in drivers:
+                    drivers.append(dn)
+                drv = drivers.index(dn)
+            paths.append(d)
+            recs.append((code, devtype, attrs, f["iface"], f["pci"], f["parent"], f["own"], 0, drv))
+    return paths, np.array(recs, dtype=b.DEV_REC), drivers
+
+
+def test_packed_filter_agrees_with_scalar_walk(tree):
+    """two restatements of the reference against each other: the library's scalar
+    mc_list_all_devices / mc_is_excluded_device walking a fake sysfs tree, and the
+    oracle's predicates over records packed from the same tree"""
+    import ctypes
+
+    from montecarlo_amd import load_library
+    from test_legacy_abi import MCDeviceInfo
+
+    lib = load_library()
+    lib.mc_list_all_devices.argtypes = [ctypes.POINTER(MCDeviceInfo), ctypes.c_int]
+    lib.mc_is_excluded_device.argtypes = [ctypes.c_char_p]
+    buf = (MCDeviceInfo * 64)()
+    n = lib.mc_list_all_devices(buf, 64)
+    listed_scalar = {os.path.realpath(buf[k].syspath.decode()) for k in range(n)}
+    paths, rec, drivers = records_from_tree(tree)
+    assert len(rec) == 24
+    arena, off = pack_strings([d.encode() for d in drivers])
+    v, kept = oracle.device_filter(rec, arena, off, np.array([0, len(rec)], np.uint32), 0)
+    listed_packed = {p for p, x in zip(paths, v) if x & 1}
+    assert listed_packed == listed_scalar and kept[1] == n
+    for p, x in zip(paths, v):
+        assert lib.mc_is_excluded_device(p.encode()) == ((x >> 1) & 1), p
