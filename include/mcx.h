@@ -317,6 +317,30 @@ int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, 
                           uint32_t kept_total, void *d_S_out, void *d_s_off_out, void *d_src,
                           uint64_t *bytes_out);
 
+/* ---- the library's name tables as data ------------------------------------ */
+
+/*
+ * The literals the reference spreads over its sources - the 113 core module
+ * names and 56 prefixes of is_safe_module (desktop/ui.py:1402-1470, 1486-1514),
+ * the 6 bus tags of a hardware alias (desktop/ui.py:1540), the 8 PCI port
+ * driver names (montecarlo/libmontecarlo.c:778-780), the rtw88 / rtl name
+ * variants (montecarlo/libmontecarlo.c:552-565) - are one table set here.
+ * The compiled-in defaults are the reference's values; a text file
+ * ("format 1", sections [core] [prefix] [hw_alias_prefix] [infra_driver]
+ * [name_variant], one entry per line, '#' comments) replaces them for the
+ * whole process: mcx_safe_module_names, the hardware-alias flags of tables
+ * loaded afterwards, mcx_device_filter, mc_is_infrastructure_device and
+ * mc_driver_is_in_use follow the active set.  Replace it before other
+ * threads use the library.  mcx_tables_dump writes the active set in the file
+ * format (buf may be NULL to learn the size); counts: core, prefix,
+ * hw_alias_prefix, infra_driver, name_variant rules.
+ */
+int mcx_tables_load_file(const char *path);
+int mcx_tables_load_text(const char *text, size_t len);
+void mcx_tables_reset(void);
+int mcx_tables_dump(char *buf, size_t cap, size_t *need);
+int mcx_tables_info(uint32_t *format, uint32_t counts[5], int *is_default);
+
 /* ---- text tables: modules.alias, modules.dep, /proc/modules ------------- */
 
 /*

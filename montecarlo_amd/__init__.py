@@ -25,6 +25,10 @@ from .binding import (  # noqa: F401
     safe_module_names,
     pack_strings,
     DEV_REC,
+    tables_load,
+    tables_reset,
+    tables_dump,
+    tables_info,
 )
 from . import synth  # noqa: F401
 

@@ -119,6 +119,14 @@ def load_library():
         "mcx_dep_graph_load_modtab": (ctypes.c_int, [_vp, _vp]),
         "mcx_safe_module_names": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
         "mcx_safe_table_sizes": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
+        "mcx_tables_load_file": (ctypes.c_int, [ctypes.c_char_p]),
+        "mcx_tables_load_text": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+        "mcx_tables_reset": (None, []),
+        "mcx_tables_dump": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+        "mcx_tables_info": (
+            ctypes.c_int,
+            [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int)],
+        ),
         "mcx_fleet_roots": (
             ctypes.c_int,
             [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64,
@@ -436,6 +444,43 @@ def safe_module_names(names):
     if rc != 0:
         raise McxError(rc, "mcx_safe_module_names")
     return out[: len(names)]
+
+
+def tables_load(path=None, text=None):
+    """replace the process-wide name tables from a file or from text"""
+    lib = load_library()
+    if path is not None:
+        rc = lib.mcx_tables_load_file(os.fsencode(path))
+    else:
+        raw = text.encode() if isinstance(text, str) else text
+        rc = lib.mcx_tables_load_text(raw, len(raw))
+    if rc != 0:
+        raise McxError(rc, "mcx_tables_load", "unreadable file or malformed table text")
+
+
+def tables_reset():
+    load_library().mcx_tables_reset()
+
+
+def tables_dump():
+    lib = load_library()
+    need = ctypes.c_size_t()
+    lib.mcx_tables_dump(None, 0, ctypes.byref(need))
+    buf = ctypes.create_string_buffer(need.value)
+    rc = lib.mcx_tables_dump(buf, need.value, ctypes.byref(need))
+    if rc != 0:
+        raise McxError(rc, "mcx_tables_dump")
+    return buf.value.decode()
+
+
+def tables_info():
+    """dict(format, core, prefix, hw_alias_prefix, infra_driver, name_variant, is_default)"""
+    lib = load_library()
+    fmt, is_default = ctypes.c_uint32(), ctypes.c_int()
+    counts = (ctypes.c_uint32 * 5)()
+    lib.mcx_tables_info(ctypes.byref(fmt), counts, ctypes.byref(is_default))
+    keys = ("core", "prefix", "hw_alias_prefix", "infra_driver", "name_variant")
+    return dict(format=fmt.value, is_default=bool(is_default.value), **dict(zip(keys, counts)))
 
 
 class ModTab:

@@ -18,6 +18,7 @@
  * the walk stops.
  */
 #include "glob_compile.h"
+#include "tables.h"
 
 #include <algorithm>
 #include <array>
@@ -151,11 +152,12 @@ static bool is_space(unsigned c)
 /* reference desktop/ui.py:1540-1549: alias_line.strip().startswith(prefix) */
 static uint8_t hw_tag_of(const uint8_t *pat, size_t n)
 {
-    static const char *tags[] = {"pci:", "usb:", "platform:", "hid:", "serio:", "of:"};
+    const mcx_tables_view *tv = mcx_tables_active(); /* the six bus tags unless a table file replaced them */
     size_t b = 0;
     while (b < n && is_space(pat[b]))
         ++b;
-    for (const char *t : tags) {
+    for (uint32_t k = 0; k < tv->count[MCX_TS_HW_PREFIX]; ++k) {
+        const char *t = tv->item[MCX_TS_HW_PREFIX][k];
         size_t tl = strlen(t);
         if (n - b >= tl && memcmp(pat + b, t, tl) == 0)
             return 1;

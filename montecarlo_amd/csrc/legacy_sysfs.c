@@ -35,6 +35,7 @@
 #include <unistd.h>
 
 #include "../../include/libmontecarlo.h"
+#include "tables.h"
 
 /* ---- helpers ---------------------------------------------------------------- */
 
@@ -327,10 +328,10 @@ int mc_is_infrastructure_device(const char *syspath, const char *subsystem)
             if (!name)
                 return 1;
             ++name;
-            static const char *const infra[] = {"pcieport", "pci_bridge", "pciehp", "pcie_aspm",
-                                                "pcie_pme", "pcie_edr", "shpchp", "piix4_smbus", NULL};
-            for (int i = 0; infra[i]; ++i)
-                if (strcmp(name, infra[i]) == 0)
+            /* the 8 port / hot-plug drivers unless a table file replaced them */
+            const mcx_tables_view *tv = mcx_tables_active();
+            for (uint32_t i = 0; i < tv->count[MCX_TS_INFRA]; ++i)
+                if (strcmp(name, tv->item[MCX_TS_INFRA][i]) == 0)
                     return 1;
         }
     }
@@ -586,12 +587,17 @@ static void driver_names(const char *module_name, char names[][128], int *count,
     strncpy(names[*count], module_name, 127);
     names[*count][127] = '\0';
     (*count)++;
-    if (strncmp(module_name, "rtw88_", 6) == 0 && *count < max_names) {
-        snprintf(names[*count], 128, "rtw_%s", module_name + 6); /* rtw88_8821cu -> rtw_8821cu */
-        (*count)++;
-    } else if (strncmp(module_name, "rtl", 3) == 0 && *count < max_names) {
-        snprintf(names[*count], 128, "rtw_%s", module_name + 3);
-        (*count)++;
+    /* the first rule whose prefix starts the name gives a second name; the
+     * default rules: rtw88_8821cu -> rtw_8821cu, else rtlX -> rtw_X */
+    const mcx_tables_view *tv = mcx_tables_active();
+    for (uint32_t k = 0; k + 1 < tv->count[MCX_TS_VARIANT] && *count < max_names; k += 2) {
+        const char *prefix = tv->item[MCX_TS_VARIANT][k];
+        const size_t pl = strlen(prefix);
+        if (strncmp(module_name, prefix, pl) == 0) {
+            snprintf(names[*count], 128, "%s%s", tv->item[MCX_TS_VARIANT][k + 1], module_name + pl);
+            (*count)++;
+            break;
+        }
     }
 }
 

@@ -22,16 +22,17 @@
 
 #include "mcx_internal.h"
 #include "mcx_scan.h"
+#include "tables.h"
 
 #define DVN_INFRA 1u   /* one of the 8 PCI port / hot-plug drivers */
 #define DVN_USBHOST 2u /* holds "hcd" or is "hub" */
 
-/* montecarlo/libmontecarlo.c:778-780 */
-__constant__ char dv_infra_names[8][12] = {"pcieport", "pci_bridge", "pciehp",  "pcie_aspm",
-                                           "pcie_pme", "pcie_edr",   "shpchp", "piix4_smbus"};
-
+/* infra: the names PCI devices are dropped for (montecarlo/libmontecarlo.c:778-785
+ * unless a table file replaced them), packed: name k = infra[infra_off[k] .. infra_off[k+1]) */
 __global__ void __launch_bounds__(FL_THREADS)
-dv_names(const char *__restrict__ arena, const uint32_t *__restrict__ off, uint32_t D, uint8_t *__restrict__ bits)
+dv_names(const char *__restrict__ arena, const uint32_t *__restrict__ off, uint32_t D,
+         const char *__restrict__ infra, const uint32_t *__restrict__ infra_off, uint32_t n_infra,
+         uint8_t *__restrict__ bits)
 {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D)
@@ -39,11 +40,14 @@ dv_names(const char *__restrict__ arena, const uint32_t *__restrict__ off, uint3
     const char *s = arena + off[d];
     const uint32_t n = off[d + 1] - off[d];
     uint32_t b = 0;
-    for (uint32_t k = 0; k < 8u; ++k) {
+    for (uint32_t k = 0; k < n_infra; ++k) {
+        const uint32_t a = infra_off[k];
+        if (infra_off[k + 1] - a != n)
+            continue;
         uint32_t i = 0;
-        while (i < n && dv_infra_names[k][i] != '\0' && dv_infra_names[k][i] == s[i])
+        while (i < n && infra[a + i] == s[i])
             ++i;
-        if (i == n && dv_infra_names[k][i] == '\0')
+        if (i == n)
             b |= DVN_INFRA;
     }
     /* strstr(name, "hcd") || strcmp(name, "hub") == 0   (libmontecarlo.c:413) */
@@ -181,20 +185,37 @@ int mcx_device_filter_dev(mcx_ctx *ctx, const void *d_rec, uint32_t N, const voi
         return MCX_OK;
     }
     const uint32_t nb = (H + SCAN_ITEMS - 1u) / SCAN_ITEMS;
-    /* scratch: name bits, per-host counts, block sums, offsets when the caller wants none, total */
+    /* the active table's driver names, packed for the device */
+    const mcx_tables_view *tv = mcx_tables_active();
+    const uint32_t n_infra = tv->count[MCX_TS_INFRA];
+    std::vector<uint32_t> infra_off(n_infra + 1, 0);
+    std::string infra;
+    for (uint32_t k = 0; k < n_infra; ++k) {
+        infra += tv->item[MCX_TS_INFRA][k];
+        infra_off[k + 1] = (uint32_t)infra.size();
+    }
+    /* scratch: name bits, per-host counts, block sums, offsets when the caller wants none, total, names */
     const size_t o_cnt = up256(D ? D : 1), o_bsum = o_cnt + up256(4 * (size_t)H);
     const size_t o_off = o_bsum + up256(4 * (size_t)nb), o_total = o_off + up256(4 * ((size_t)H + 1));
+    const size_t o_ioff = o_total + 256, o_infra = o_ioff + up256(4 * infra_off.size());
     void *base;
-    int rc = mcx_scratch(ctx, o_total + 256, &base);
+    int rc = mcx_scratch(ctx, o_infra + up256(infra.size() + 1), &base);
     if (rc != MCX_OK)
         return rc;
+    /* pageable sources: the copies are done when the calls return */
+    HIPCHK(ctx, hipMemcpyAsync((char *)base + o_ioff, infra_off.data(), 4 * infra_off.size(), hipMemcpyHostToDevice,
+                               ctx->stream));
+    if (!infra.empty())
+        HIPCHK(ctx, hipMemcpyAsync((char *)base + o_infra, infra.data(), infra.size(), hipMemcpyHostToDevice,
+                                   ctx->stream));
     uint8_t *d_bits = (uint8_t *)base;
     uint32_t *d_cnt = (uint32_t *)((char *)base + o_cnt), *d_bsum = (uint32_t *)((char *)base + o_bsum);
     uint32_t *d_off = d_kept_off ? (uint32_t *)d_kept_off : (uint32_t *)((char *)base + o_off);
     unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
     if (D)
         dv_names<<<(D + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
-            (const char *)d_drv_arena, (const uint32_t *)d_drv_off, D, d_bits);
+            (const char *)d_drv_arena, (const uint32_t *)d_drv_off, D, (const char *)base + o_infra,
+            (const uint32_t *)((char *)base + o_ioff), n_infra, d_bits);
     if (N)
         dv_classify<<<(N + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
             (const uint4 *)d_rec, N, d_bits, D, (uint8_t *)d_verdict);

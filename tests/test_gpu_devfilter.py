@@ -125,3 +125,30 @@ def test_edge_cases(gpu_ctx):
     with pytest.raises(McxError):
         gpu_ctx.device_filter_dev(d.ptr + 4, 1, None, None, 0, d.ptr, 1, 0, d.ptr, None)   # misaligned records
     d.free()
+
+
+def test_replaced_tables_reach_the_device(gpu_ctx):
+    """driver names and bus tags come from the active table set, also on the GPU"""
+    import montecarlo_amd as m
+
+    rec = np.zeros(3, dtype=b.DEV_REC)
+    rec["subsystem"] = b.SUB_PCI
+    rec["driver"] = [0, 1, 2]
+    arena, off = pack_strings([b"pcieport", b"ahci", b"nvme"])
+    one_host = np.array([0, 3], np.uint32)
+    A, a_off = pack_strings([b"pci:v00008086*", b"acpi*:PNP0C09:*", b"usb:v1234*"])
+    a_mod = np.array([0, 1, 2], dtype=np.uint32)
+    try:
+        v, _ = gpu_ctx.device_filter(rec, arena, off, one_host)
+        assert (v & 1).tolist() == [0, 1, 1]
+        gpu_ctx.alias_table_load(A, a_off, a_mod)
+        assert gpu_ctx.alias_hw_flags(3).tolist() == [1, 0, 1]
+        m.tables_load(text="format 1\n[infra_driver]\nahci\nnvme\n[hw_alias_prefix]\nacpi\n")
+        v, _ = gpu_ctx.device_filter(rec, arena, off, one_host)
+        assert (v & 1).tolist() == [1, 0, 0] and (v >> 4).tolist() == [0, 3, 3]
+        gpu_ctx.alias_table_load(A, a_off, a_mod)
+        assert gpu_ctx.alias_hw_flags(3).tolist() == [0, 1, 0]
+    finally:
+        m.tables_reset()
+    v, _ = gpu_ctx.device_filter(rec, arena, off, one_host)
+    assert (v & 1).tolist() == [0, 1, 1]
