@@ -116,6 +116,21 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
 /* Same with everything resident on the device; enqueues and returns. */
 int mcx_alias_match_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N,
                         void *d_first_idx, void *d_count);
+/*
+ * Every matching table position per string, ascending - the order in which
+ * kmod lists the modules of a modalias (all matching lines of modules.alias,
+ * in file order).  CSR output: list_off[i] .. list_off[i+1] index list_idx;
+ * with K > 0 only the first K positions of a string are kept (K = 0: all).
+ * *total_out = list_off[N]; when list_idx (cap entries) is too small the call
+ * returns MCX_E_TOO_LARGE with *total_out and list_off filled in.  Costs two
+ * passes of the match (count, then fill).  Strings that kmod would refuse
+ * (MCX_TABLE_NORMALIZE_DASH tables) have empty lists.
+ */
+int mcx_alias_match_list(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, uint32_t K,
+                         uint32_t *list_off, uint32_t *list_idx, uint64_t cap, uint64_t *total_out);
+int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, uint32_t K,
+                             void *d_list_off, void *d_list_idx, uint64_t cap, uint64_t *total_out);
+
 /* driver_mod[i] = a_mod[first_idx[i]] (MCX_NO_MATCH if none); device buffers. */
 int mcx_alias_driver_mod_dev(mcx_ctx *ctx, const void *d_first_idx, uint32_t N,
                              void *d_driver_mod);

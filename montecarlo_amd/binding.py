@@ -76,6 +76,14 @@ def load_library():
         "mcx_alias_table_load": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32]),
         "mcx_alias_match": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, _vp, _vp]),
         "mcx_alias_match_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, _vp, _vp]),
+        "mcx_alias_match_list": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_alias_match_list_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
+        ),
         "mcx_alias_driver_mod_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
         "mcx_alias_hw_flags": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
         "mcx_alias_table_info": (
@@ -395,6 +403,30 @@ class Context:
             self._check(rc, "mcx_fleet_roots_dev")
         return total.value
 
+
+    def alias_match_list(self, S, s_off, K=0, cap=None):
+        """(list_off, list_idx) of mcx_alias_match_list; sizes list_idx itself when cap is None"""
+        S, s_off = _as(S, np.uint8), _as(s_off, np.uint32)
+        N = len(s_off) - 1
+        off = np.zeros(N + 1, dtype=np.uint32)
+        total = ctypes.c_uint64()
+        idx = np.zeros(int(cap) if cap else 1, dtype=np.uint32)
+        args = (self.h, _ptr(S) if len(S) else None, _ptr(s_off), N, int(K), _ptr(off))
+        rc = self.lib.mcx_alias_match_list(*args, _ptr(idx), int(cap) if cap else 0, ctypes.byref(total))
+        if rc == -6 and cap is None and total.value < 2**32:
+            idx = np.zeros(total.value, dtype=np.uint32)
+            rc = self.lib.mcx_alias_match_list(*args, _ptr(idx), total.value, ctypes.byref(total))
+        self._check(rc, "mcx_alias_match_list")
+        return off, idx[: total.value]
+
+    def alias_match_list_dev(self, d_S, d_s_off, N, K, d_list_off, d_list_idx, cap, size_only=False):
+        """returns the total; with size_only a too-small list_idx is not an error"""
+        total = ctypes.c_uint64()
+        rc = self.lib.mcx_alias_match_list_dev(self.h, d_S, d_s_off, N, int(K), d_list_off, d_list_idx, int(cap),
+                                               ctypes.byref(total))
+        if not (size_only and rc == -6 and cap < total.value < 2**32):
+            self._check(rc, "mcx_alias_match_list_dev")
+        return total.value
 
     # ---- fleet inventory predicates ------------------------------------------
     def device_filter(self, rec, drv_arena, drv_off, dev_off, max_per_host=0):

@@ -492,6 +492,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     /* patterns with the same text are indexed once, under their first position */
     std::unordered_map<std::string, uint32_t> seen;
     seen.reserve(P);
+    std::unordered_map<uint32_t, std::vector<uint32_t>> repeats; /* first position -> later positions */
     for (uint32_t j = 0; j < P; ++j) {
         if (a_off[j + 1] < a_off[j]) {
             err = "a_off not monotonic at pattern " + std::to_string(j);
@@ -503,8 +504,10 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         auto ins = seen.emplace(std::string((const char *)pat, n), j);
         if (!ins.second) {
             /* a repeat: parsed (and, if need be, refused) when first seen */
-            if (mult[ins.first->second])
+            if (mult[ins.first->second]) {
                 mult[ins.first->second]++;
+                repeats[ins.first->second].push_back(j);
+            }
             continue;
         }
         std::string e;
@@ -536,6 +539,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     out.n_distinct = (uint32_t)n_idx;
     out.slot.assign(n_idx * (size_t)MCX_SLOT_WORDS, 0u);
     out.sig.resize(n_idx);
+    out.dup_start.assign(n_idx ? n_idx : 1, 0u);
     struct Group {
         uint32_t start, count;
     };
@@ -551,7 +555,15 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         mcx_fill_slot(irs[j], (uint32_t)keys[j].size(), j, mult[j], out.sets,
                       &out.slot[k * (size_t)MCX_SLOT_WORDS], out.ext);
         out.sig[k] = sig_of(irs[j], keys[j].size());
+        if (mult[j] > 1u) {
+            out.dup_start[k] = (uint32_t)out.dup_idx.size();
+            out.dup_idx.push_back(j);
+            const std::vector<uint32_t> &later = repeats[j];
+            out.dup_idx.insert(out.dup_idx.end(), later.begin(), later.end());
+        }
     }
+    if (out.dup_idx.empty())
+        out.dup_idx.push_back(0u);
     /* the matchers read up to two words past a program, the screen up to three
      * signatures past a group: keep them in bounds */
     out.sig.insert(out.sig.end(), 4, 0u);

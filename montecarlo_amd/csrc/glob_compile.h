@@ -38,6 +38,10 @@ struct mcx_compiled_table {
     std::vector<uint32_t> lens;      /* distinct key lengths, ascending       */
     std::vector<uint32_t> sets;      /* distinct bracket sets, 8 words each   */
     std::map<std::array<uint32_t, 8>, uint32_t> set_ids; /* set bits -> number */
+    /* table positions of repeated pattern texts: the copies of the pattern in
+     * slot k are dup_idx[dup_start[k] .. dup_start[k] + mult), ascending
+     * (dup_start is only meaningful where mult > 1) */
+    std::vector<uint32_t> dup_start, dup_idx;
     std::vector<uint8_t> hw_tag;     /* P bytes: pattern text starts with one
                                         of the six hardware bus tags          */
 };

@@ -21,6 +21,9 @@ void mcx_free_table(mcx_ctx *ctx)
     (void)hipFree(ctx->d_sets);
     (void)hipFree(ctx->d_amod);
     (void)hipFree(ctx->d_hwtag);
+    (void)hipFree(ctx->d_dup_start);
+    (void)hipFree(ctx->d_dup_idx);
+    ctx->d_dup_start = ctx->d_dup_idx = nullptr;
     ctx->d_slot = nullptr;
     ctx->d_ext = nullptr;
     ctx->d_sig = nullptr;

@@ -33,6 +33,8 @@ struct mcx_ctx {
     uint32_t *d_slot = nullptr;      /* n_indexed program slots, index order   */
     uint32_t *d_ext = nullptr;       /* overflow programs                      */
     uint32_t *d_sig = nullptr;       /* n_indexed gram signatures (+ padding)  */
+    uint32_t *d_dup_start = nullptr; /* per slot: where its copies start in d_dup_idx (mult > 1 only) */
+    uint32_t *d_dup_idx = nullptr;   /* table positions of repeated pattern texts */
     uint32_t *d_lens = nullptr;      /* nlens distinct key lengths             */
     mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
     uint32_t slot_mask = 0;

@@ -9,6 +9,7 @@
 
 #include "glob_compile.h"
 #include "mcx_internal.h"
+#include "mcx_scan.h"
 
 /* ------------------------------------------------------------------------- */
 /* K1: alias match                                                            */
@@ -39,6 +40,15 @@ struct k1_table_t {
     uint32_t nlens;
     uint32_t nlens_magic;   /* ceil(2^32 / nlens): x / nlens = mulhi(x, magic) for x < 2^16 */
     uint32_t norm_dash;     /* strings get kmod's '-' -> '_' rule before they are matched */
+};
+
+/* where the list variant of the kernel writes: string i owns
+ * idx[off[i] .. off[i+1]), as many entries as the counting pass found */
+struct k1_list_t {
+    const uint32_t *off;
+    uint32_t *idx;
+    const uint32_t *dup_start; /* per slot: its copies in dup_idx, for slots with a multiplicity above 1 */
+    const uint32_t *dup_idx;
 };
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
@@ -222,11 +232,11 @@ __device__ __attribute__((noinline)) void k1_normalize_tile(uint32_t *str_w, con
     }
 }
 
-template <bool BULK>
+template <bool BULK, bool LIST>
 __global__ void __launch_bounds__(K1_THREADS, 4)
 k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
                  uint32_t str_cap, uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
-                 uint32_t *__restrict__ count
+                 uint32_t *__restrict__ count, const k1_list_t L
 #ifdef MCX_K1_STAMPS
                  , unsigned long long *__restrict__ stamps
 #endif
@@ -289,7 +299,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         uint32_t so = s_off[t0 + i];
         str_at[i] = so - gbase + shift;
         str_len[i] = s_off[t0 + i + 1] - so;
-        res_first[i] = MCX_NO_MATCH;
+        /* list variant: res_first holds where the string's list starts, res_count its fill */
+        res_first[i] = LIST ? L.off[t0 + i] : MCX_NO_MATCH;
         res_count[i] = 0;
         refused[i] = 0;
     }
@@ -468,6 +479,24 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             return mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets);
         return mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len, T.norm_dash}, len, T.sets);
     };
+    /* pattern in slot kk (table position orig, mult copies of its text) matches string `slot` */
+    auto hit = [&](uint32_t slot, uint32_t kk, uint32_t orig, uint32_t mult) __attribute__((always_inline)) {
+        if constexpr (LIST) {
+            if (!refused[slot]) {
+                uint32_t *dst = L.idx + res_first[slot] + atomicAdd(&res_count[slot], mult);
+                if (mult == 1u) {
+                    dst[0] = orig;
+                } else {
+                    const uint32_t *src = L.dup_idx + L.dup_start[kk];
+                    for (uint32_t m = 0; m < mult; ++m)
+                        dst[m] = src[m];
+                }
+            }
+        } else {
+            atomicMin(&res_first[slot], orig);
+            atomicAdd(&res_count[slot], mult);
+        }
+    };
     uint32_t *my_stage = stage[BULK ? 0u : wave];
     /* many strings per block: a lane per survivor, its slot read in place; the
      * waves of the other blocks on the CU cover the memory latency */
@@ -486,10 +515,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 LdsOcc occ{(lds_words_t)occ_w + slot * K1_OCC_WORDS};
                 ok = mcx_slot_match_occ(GlobalProg{sp}, occ, len, T.sets);
             }
-            if (ok) {
-                atomicMin(&res_first[slot], sp[1]);
-                atomicAdd(&res_count[slot], sp[MCX_SLOT_MULT]);
-            }
+            if (ok)
+                hit(slot, e & 0x03FFFFFFu, sp[1], sp[MCX_SLOT_MULT]);
         }
     };
     auto run_groups = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
@@ -569,10 +596,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 }
                 ok = pre && k == 7u && MCX_STATE_OK(state) != 0u;
             }
-            if (ok) {
-                atomicMin(&res_first[slot], lp[1]);
-                atomicAdd(&res_count[slot], lp[MCX_SLOT_MULT]);
-            }
+            if (ok)
+                hit(slot, ring[(from + g) & (K1_RING - 1u)] & 0x03FFFFFFu, lp[1], lp[MCX_SLOT_MULT]);
             K1_TOCK(acc_comb);
 #ifdef MCX_K1_STAMPS
             ++acc_n;
@@ -694,9 +719,11 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     __syncthreads();
     K1_STAMP(5);
-    for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
-        first_idx[t0 + i] = refused[i] ? MCX_NO_MATCH : res_first[i];
-        count[t0 + i] = refused[i] ? 0u : res_count[i];
+    if constexpr (!LIST) {
+        for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
+            first_idx[t0 + i] = refused[i] ? MCX_NO_MATCH : res_first[i];
+            count[t0 + i] = refused[i] ? 0u : res_count[i];
+        }
     }
     K1_STAMP(6);
 #ifdef MCX_K1_STAMPS
@@ -707,6 +734,48 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         stamps[blockIdx.x * 16u + 13u] = acc_n;
     }
 #endif
+}
+
+/* one thread per string: its list in ascending table order (lists are short:
+ * a handful of entries; insertion sort in place) */
+__global__ void __launch_bounds__(256)
+k1_list_sort(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    uint32_t *a = idx + off[i];
+    const uint32_t n = off[i + 1] - off[i];
+    for (uint32_t k = 1; k < n; ++k) {
+        const uint32_t v = a[k];
+        uint32_t j = k;
+        while (j > 0u && a[j - 1u] > v) {
+            a[j] = a[j - 1u];
+            --j;
+        }
+        a[j] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k1_list_cap(const uint32_t *__restrict__ count, uint32_t N, uint32_t K, uint32_t *__restrict__ capped)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N)
+        capped[i] = count[i] < K ? count[i] : K;
+}
+
+/* the first entries of every sorted list: from[i] .. -> to[i] .. to[i+1] */
+__global__ void __launch_bounds__(256)
+k1_list_take(const uint32_t *__restrict__ from_off, const uint32_t *__restrict__ from_idx,
+             const uint32_t *__restrict__ to_off, uint32_t N, uint32_t *__restrict__ to_idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const uint32_t a = from_off[i], b = to_off[i], n = to_off[i + 1] - b;
+    for (uint32_t k = 0; k < n; ++k)
+        to_idx[b + k] = from_idx[a + k];
 }
 
 __global__ void __launch_bounds__(256)
@@ -761,6 +830,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
         (rc = mcx_dev_upload(ctx, &ctx->d_ext, t.ext.data(), t.ext.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_sig, t.sig.data(), t.sig.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_lens, t.lens.data(), t.lens.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_dup_start, t.dup_start.data(), t.dup_start.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_dup_idx, t.dup_idx.data(), t.dup_idx.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_slots, t.slots.data(), t.slots.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_sets, t.sets.data(), t.sets.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_amod, a_mod, (size_t)P)) != 0 ||
@@ -774,7 +845,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     ctx->slot_mask = (uint32_t)t.slots.size() - 1u;
     ctx->nlens = (uint32_t)t.lens.size();
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
-    ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.sets.size() + t.lens.size()) +
+    ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.sets.size() + t.lens.size() +
+                                      t.dup_start.size() + t.dup_idx.size()) +
                        sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + 4 * (uint64_t)P + t.hw_tag.size();
     ctx->table_loaded = true;
     return MCX_OK;
@@ -806,8 +878,12 @@ extern "C" int mcx_debug_k1_stamps(unsigned long long *out, uint32_t max_blocks)
 }
 #endif
 
+/* list_off == nullptr: first_idx / count.  Otherwise the list variant: every
+ * match is written into d_list_idx at the place list_off (the exclusive sums
+ * of a counting pass over the same strings) gives its string. */
 static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
-                              uint32_t *d_first, uint32_t *d_count)
+                              uint32_t *d_first, uint32_t *d_count, const uint32_t *d_list_off = nullptr,
+                              uint32_t *d_list_idx = nullptr)
 {
     if (N == 0)
         return MCX_OK;
@@ -841,19 +917,27 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     if (!g_k1_stamps)
         (void)hipMalloc((void **)&g_k1_stamps, 16u * 8u * 65536u);
     g_k1_stamp_blocks = blocks < 65536u ? blocks : 65536u;
-    k1_match_indexed<false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T,
-                                                                      d_first, d_count, g_k1_stamps);
+    k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned,
+                                                                             T, d_first, d_count, k1_list_t{},
+                                                                             g_k1_stamps);
 #else
     /* eight lanes per survivor while a block's waves see few survivors at a
      * time; a lane per survivor once every pass fills its wave (measured: the
      * two meet at about 10^5 strings against 3 x 10^4 patterns) */
     const bool bulk = N >= 65536u;
-    if (bulk)
-        k1_match_indexed<true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned,
-                                                                         T, d_first, d_count);
+    const k1_list_t L{d_list_off, d_list_idx, ctx->d_dup_start, ctx->d_dup_idx};
+    if (d_list_off && bulk)
+        k1_match_indexed<true, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
+                                                                               s_aligned, T, nullptr, nullptr, L);
+    else if (d_list_off)
+        k1_match_indexed<false, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
+                                                                                s_aligned, T, nullptr, nullptr, L);
+    else if (bulk)
+        k1_match_indexed<true, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
+                                                                                s_aligned, T, d_first, d_count, L);
     else
-        k1_match_indexed<false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned,
-                                                                          T, d_first, d_count);
+        k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
+                                                                                 s_aligned, T, d_first, d_count, L);
 #endif
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
@@ -921,6 +1005,145 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
     HIPCHK(ctx, hipMemcpyAsync(count, d_count, 4 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MCX_OK;
+}
+
+int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, uint32_t K,
+                             void *d_list_off, void *d_list_idx, uint64_t cap, uint64_t *total_out)
+{
+    if (!ctx || !d_s_off || !d_list_off || !total_out || (cap && !d_list_idx))
+        return MCX_E_BAD_ARG;
+    if (!ctx->table_loaded)
+        return MCX_E_NOT_LOADED;
+    *total_out = 0;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    if (N == 0) {
+        HIPCHK(ctx, hipMemsetAsync(d_list_off, 0, 4, ctx->stream));
+        return MCX_OK;
+    }
+#ifdef MCX_K1_STAMPS
+    ctx->err = "the diagnostic build has no list variant";
+    return MCX_E_BAD_ARG;
+#else
+    const uint32_t nb = (N + SCAN_ITEMS - 1u) / SCAN_ITEMS, grid = (N + 255u) / 256u;
+    /* scratch: first, count, offsets of the full lists, capped counts, block sums, two totals */
+    const size_t words = up256(4 * ((size_t)N + 1));
+    const size_t o_count = words, o_full = 2 * words, o_cap = 3 * words, o_bsum = 4 * words;
+    const size_t o_total = o_bsum + up256(4 * (size_t)nb);
+    void *base;
+    int rc = mcx_scratch(ctx, o_total + 256, &base);
+    if (rc != MCX_OK)
+        return rc;
+    uint32_t *d_first = (uint32_t *)base, *d_count = (uint32_t *)((char *)base + o_count);
+    uint32_t *d_full = (uint32_t *)((char *)base + o_full), *d_capped = (uint32_t *)((char *)base + o_cap);
+    uint32_t *d_bsum = (uint32_t *)((char *)base + o_bsum);
+    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
+    unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
+    /* counting pass, then the places of the lists */
+    if ((rc = launch_alias_match(ctx, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N, d_first, d_count)) != MCX_OK)
+        return rc;
+    uint32_t *full_off = K ? d_full : (uint32_t *)d_list_off;
+    mcx_scan_enqueue(ctx->stream, d_count, N, d_bsum, d_total, full_off);
+    if (K) {
+        k1_list_cap<<<grid, 256, 0, ctx->stream>>>(d_count, N, K, d_capped);
+        mcx_scan_enqueue(ctx->stream, d_capped, N, d_bsum, d_total + 1, (uint32_t *)d_list_off);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(h_total, d_total, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long all = h_total[0], kept = K ? h_total[1] : all;
+    *total_out = kept;
+    if (all > 0xFFFFFFFFull) {
+        ctx->err = "more than 2^32 - 1 matches: split the batch";
+        return MCX_E_TOO_LARGE;
+    }
+    if (kept > cap) {
+        ctx->err = "list_idx too small: " + std::to_string(kept) + " entries needed";
+        return MCX_E_TOO_LARGE;
+    }
+    if (all == 0)
+        return MCX_OK;
+    /* filling pass; with a limit the full lists go to a temporary array first */
+    uint32_t *full_idx = (uint32_t *)d_list_idx;
+    if (K) {
+        if (hipMalloc((void **)&full_idx, 4 * (size_t)all) != hipSuccess) {
+            ctx->err = "hipMalloc of the full match lists failed";
+            return MCX_E_NOMEM;
+        }
+    }
+    rc = launch_alias_match(ctx, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N, nullptr, nullptr, full_off,
+                            full_idx);
+    if (rc == MCX_OK) {
+        k1_list_sort<<<grid, 256, 0, ctx->stream>>>(full_off, N, full_idx);
+        if (K)
+            k1_list_take<<<grid, 256, 0, ctx->stream>>>(full_off, full_idx, (const uint32_t *)d_list_off, N,
+                                                        (uint32_t *)d_list_idx);
+        if (hipGetLastError() != hipSuccess)
+            rc = MCX_E_HIP;
+    }
+    if (K) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(full_idx);
+    }
+    return rc;
+#endif
+}
+
+int mcx_alias_match_list(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, uint32_t K,
+                         uint32_t *list_off, uint32_t *list_idx, uint64_t cap, uint64_t *total_out)
+{
+    if (!ctx || !s_off || !list_off || !total_out || (cap && !list_idx))
+        return MCX_E_BAD_ARG;
+    if (!ctx->table_loaded)
+        return MCX_E_NOT_LOADED;
+    *total_out = 0;
+    list_off[0] = 0;
+    if (N == 0)
+        return MCX_OK;
+    if (!S && s_off[N] != 0)
+        return MCX_E_BAD_ARG;
+    for (uint32_t i = 0; i < N; ++i)
+        if (s_off[i + 1] < s_off[i]) {
+            ctx->err = "s_off not monotonic";
+            return MCX_E_BAD_ARG;
+        }
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    const size_t sbytes = s_off[N];
+    const size_t o_off = up256(sbytes ? sbytes : 1), o_loff = o_off + up256(4 * ((size_t)N + 1));
+    const size_t o_idx = o_loff + up256(4 * ((size_t)N + 1)), bytes = o_idx + up256(4 * (size_t)(cap ? cap : 1));
+    char *d = nullptr;
+    if (hipMalloc((void **)&d, bytes) != hipSuccess) {
+        ctx->err = "hipMalloc of the staging buffers failed";
+        return MCX_E_NOMEM;
+    }
+    hipError_t e = hipSuccess;
+    if (sbytes)
+        e = hipMemcpyAsync(d, S, sbytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d + o_off, s_off, 4 * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream);
+    int rc = MCX_OK;
+    if (e != hipSuccess) {
+        ctx->err = std::string("copy in: ") + hipGetErrorString(e);
+        rc = MCX_E_HIP;
+    }
+    if (rc == MCX_OK)
+        rc = mcx_alias_match_list_dev(ctx, d, d + o_off, N, K, d + o_loff, cap ? d + o_idx : nullptr, cap, total_out);
+    /* the offsets are valid even when list_idx was too small */
+    if (rc == MCX_OK || (rc == MCX_E_TOO_LARGE && *total_out > cap && *total_out <= 0xFFFFFFFFull)) {
+        e = hipMemcpyAsync(list_off, d + o_loff, 4 * ((size_t)N + 1), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == MCX_OK && *total_out)
+            e = hipMemcpyAsync(list_idx, d + o_idx, 4 * (size_t)*total_out, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->err = std::string("copy back: ") + hipGetErrorString(e);
+            rc = MCX_E_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
 }
 
 int mcx_alias_driver_mod_dev(mcx_ctx *ctx, const void *d_first_idx, uint32_t N, void *d_driver_mod)

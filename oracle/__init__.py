@@ -47,6 +47,8 @@ def oracle():
         lib.orc_has_hw_alias.argtypes = [ctypes.c_char_p]
         lib.orc_fleet_roots.restype = u64
         lib.orc_fleet_roots.argtypes = [_vp, _vp, u32, _vp, _vp, u32, _vp, _vp, _vp, _vp, _vp, _vp]
+        lib.orc_alias_match_list.restype = u64
+        lib.orc_alias_match_list.argtypes = [_vp, _vp, u32, _vp, _vp, u32, ctypes.c_int, u32, _vp, _vp]
         lib.orc_device_filter.restype = None
         lib.orc_device_filter.argtypes = [_vp, u32, _vp, _vp, u32, _vp, u32, u32, _vp, _vp]
         _ORC = lib
@@ -101,6 +103,20 @@ def alias_match(arena, a_off, S, s_off, normalize_dash=False, i0=0, i1=None, use
         oracle().orc_alias_match(_p(A), _p(a_off), P, _p(SS), _p(s_off), i0, i1, int(normalize_dash),
                                  _p(first), _p(count))
     return first[i0:i1], count[i0:i1]
+
+
+def alias_match_list(arena, a_off, S, s_off, K=0, normalize_dash=False):
+    """(list_off, list_idx): every matching table position per string in table order, first K if K > 0"""
+    a_off = np.ascontiguousarray(a_off, dtype=np.uint32)
+    s_off = np.ascontiguousarray(s_off, dtype=np.uint32)
+    P, N = len(a_off) - 1, len(s_off) - 1
+    A, SS = _c(arena, np.uint8), _c(S, np.uint8)
+    off = np.zeros(N + 1, dtype=np.uint32)
+    args = (_p(A), _p(a_off), P, _p(SS), _p(s_off), N, int(normalize_dash), int(K), _p(off))
+    total = oracle().orc_alias_match_list(*args, None)
+    idx = np.zeros(max(total, 1), dtype=np.uint32)
+    oracle().orc_alias_match_list(*args, _p(idx))
+    return off, idx[:total]
 
 
 def dep_flags(rowptr, col, in_flags):

@@ -451,6 +451,61 @@ uint64_t orc_fleet_roots(const uint32_t *rowptr, const uint32_t *col, uint32_t V
     return total;
 }
 
+/*
+ * All matching table positions per string, in table order (what kmod's
+ * `modprobe -R` prints module by module), the first K of them when K > 0.
+ * list_idx may be NULL to count only.  Returns list_off[N].
+ */
+uint64_t orc_alias_match_list(const char *arena, const uint32_t *a_off, uint32_t P, const char *S,
+                              const uint32_t *s_off, uint32_t N, int normalize_dash, uint32_t K,
+                              uint32_t *list_off, uint32_t *list_idx)
+{
+    size_t abytes = a_off[P] + (size_t)P + 1, maxlen = 0;
+    char *pat = (char *)malloc(abytes);
+    size_t *pstart = (size_t *)malloc(sizeof(size_t) * ((size_t)P + 1));
+    size_t w = 0;
+    for (uint32_t j = 0; j < P; ++j) {
+        size_t n = a_off[j + 1] - a_off[j];
+        pstart[j] = w;
+        memcpy(pat + w, arena + a_off[j], n);
+        pat[w + n] = 0;
+        if (normalize_dash && !orc_normalize(pat + w))
+            pstart[j] = (size_t)-1;
+        w += n + 1;
+    }
+    for (uint32_t i = 0; i < N; ++i)
+        if (s_off[i + 1] - s_off[i] > maxlen)
+            maxlen = s_off[i + 1] - s_off[i];
+    char *str = (char *)malloc(maxlen + 1);
+    orc_locale_t l;
+    orc_enter_c_locale(&l);
+    uint64_t total = 0;
+    list_off[0] = 0;
+    for (uint32_t i = 0; i < N; ++i) {
+        size_t n = s_off[i + 1] - s_off[i];
+        memcpy(str, S + s_off[i], n);
+        str[n] = 0;
+        int ok = normalize_dash ? orc_normalize(str) : 1;
+        uint32_t kept = 0;
+        for (uint32_t j = 0; ok && j < P && (K == 0 || kept < K); ++j) {
+            if (pstart[j] == (size_t)-1)
+                continue;
+            if (fnmatch(pat + pstart[j], str, 0) == 0) {
+                if (list_idx)
+                    list_idx[total + kept] = j;
+                ++kept;
+            }
+        }
+        total += kept;
+        list_off[i + 1] = (uint32_t)total;
+    }
+    orc_leave_c_locale(&l);
+    free(str);
+    free(pstart);
+    free(pat);
+    return total;
+}
+
 /* ---- fleet inventory: the device list of each host ------------------------ */
 
 /*

@@ -71,6 +71,46 @@ def test_k1_kmod_fixture(gpu_ctx, oracle_mod):
             assert mods[first[i]] == q["modules"][0]
 
 
+def test_k1_match_lists(gpu_ctx, oracle_mod):
+    """all matching table positions per string, ascending: kmod's answers of the
+    fixture in kmod's order, then seeded tables against the oracle (with repeated
+    pattern texts, with and without a limit, both kernel variants)"""
+    fx = load("kmod_resolve.json")
+    pats = [a[0].encode() for a in fx["aliases"]]
+    mods = [a[1] for a in fx["aliases"]]
+    A, a_off = pack_strings(pats)
+    S, s_off = pack_strings([q["query"].encode() for q in fx["queries"]])
+    gpu_ctx.alias_table_load(A, a_off, np.arange(len(pats), dtype=np.uint32), flags=1)
+    off, idx = gpu_ctx.alias_match_list(S, s_off)
+    for i, q in enumerate(fx["queries"]):
+        assert [mods[j] for j in idx[off[i]:off[i + 1]]] == q["modules"], q
+    for seed, P, N, K in ((12, 3000, 700, 0), (13, 3000, 700, 2), (14, 500, 70000, 0), (15, 500, 70000, 3)):
+        A, a_off, a_mod = synth.alias_table(seed, P)
+        # repeat a tenth of the table at the end: same texts at later positions
+        pats = [A[a_off[j]:a_off[j + 1]].tobytes() for j in range(P)]
+        pats += pats[:: 10]
+        A2, a2_off = pack_strings(pats)
+        S, s_off = synth.modalias_strings(seed, P, N)
+        gpu_ctx.alias_table_load(A2, a2_off, np.zeros(len(pats), dtype=np.uint32))
+        off, idx = gpu_ctx.alias_match_list(S, s_off, K=K)
+        first, count = gpu_ctx.alias_match(S, s_off)
+        want_n = np.minimum(count, K) if K else count
+        assert np.array_equal(np.diff(off.astype(np.int64)), want_n)
+        assert np.array_equal(idx[off[:-1][want_n > 0]], first[want_n > 0])
+        sample = np.unique(np.concatenate([np.arange(0, N, max(1, N // 400)), np.argsort(-count.astype(np.int64))[:20]]))
+        Ss, ss_off = pack_strings([S[s_off[i]:s_off[i + 1]].tobytes() for i in sample])
+        o_off, o_idx = oracle_mod.alias_match_list(A2, a2_off, Ss, ss_off, K=K)
+        for n, i in enumerate(sample):
+            assert np.array_equal(idx[off[i]:off[i + 1]], o_idx[o_off[n]:o_off[n + 1]]), i
+        assert (count > 1).any()
+    # a list that is too small: error, total and offsets still reported; an empty batch
+    with pytest.raises(McxError) as e:
+        gpu_ctx.alias_match_list(S, s_off, cap=5)
+    assert e.value.rc == -6
+    off, idx = gpu_ctx.alias_match_list(np.zeros(0, np.uint8), np.zeros(1, np.uint32))
+    assert off.tolist() == [0] and len(idx) == 0
+
+
 @pytest.mark.parametrize("seed,P,N", [(2, 30000, 1000), (5, 777, 130), (6, 63, 1), (7, 5, 65), (8, 4096, 64)])
 def test_k1_synthetic_vs_oracle(gpu_ctx, oracle_mod, seed, P, N):
     """configs[1] (1000 x 30000, seed 2) and ragged shapes around the tile sizes"""

@@ -132,6 +132,26 @@ def test_oracle_reproduces_kmod_resolution(oracle_mod):
     assert diff and all("-" in d or "_" in d for d in diff)
 
 
+def test_oracle_match_lists_reproduce_kmod_order(oracle_mod):
+    """every module kmod 29 printed for a query, in its order = the oracle's match list"""
+    fx = load("kmod_resolve.json")
+    pats = [a[0].encode() for a in fx["aliases"]]
+    mods = [a[1] for a in fx["aliases"]]
+    A, a_off = pack_strings(pats)
+    S, s_off = pack_strings([q["query"].encode() for q in fx["queries"]])
+    off, idx = oracle_mod.alias_match_list(A, a_off, S, s_off, normalize_dash=True)
+    multi = 0
+    for i, q in enumerate(fx["queries"]):
+        assert [mods[j] for j in idx[off[i]:off[i + 1]]] == q["modules"], q
+        multi += len(q["modules"]) > 1
+    assert multi >= 1
+    first, count = oracle_mod.alias_match(A, a_off, S, s_off, normalize_dash=True)
+    assert np.array_equal(np.diff(off.astype(np.int64)), count)
+    off2, idx2 = oracle_mod.alias_match_list(A, a_off, S, s_off, K=1, normalize_dash=True)
+    assert np.array_equal(np.diff(off2.astype(np.int64)), np.minimum(count, 1))
+    assert np.array_equal(idx2, first[count > 0])
+
+
 # ---- synthetic tables: twin == oracle -----------------------------------------
 
 @pytest.mark.parametrize("seed,P,N", [(2, 3000, 200), (5, 500, 300), (9, 64, 64)])
