@@ -126,10 +126,6 @@ struct LdsOcc {
         return (uint64_t)w[2u * b] | ((uint64_t)w[2u * b + 1u] << 32);
     }
 };
-struct LdsBloom {
-    lds_words_t w;
-    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return w[i]; }
-};
 
 struct __attribute__((aligned(4))) k1_sig4_t {
     uint32_t v[4]; /* gram signatures of four consecutive patterns */
@@ -265,7 +261,10 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     __shared__ uint32_t ring[K1_RING];
     __shared__ uint32_t stage[BULK ? 1 : K1_WAVES][BULK ? 1 : K1_STAGE_WORDS];
     constexpr uint32_t GROUP = BULK ? 64u : K1_GROUP; /* survivors one wave takes per pass */
-    __shared__ uint32_t bloom[K1_MAX_SPB][MCX_BLOOM_WORDS];
+    /* gram set of each string, one byte per bit number: the screen reads it with
+     * byte loads at (set + bit), no shifts, and the gram pass fills it with plain
+     * byte stores */
+    __shared__ __attribute__((aligned(4))) uint8_t bloom[K1_MAX_SPB][256];
     __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
     __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB], refused[K1_MAX_SPB];
     __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
@@ -304,12 +303,12 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         res_count[i] = 0;
         refused[i] = 0;
     }
-    for (uint32_t w = tid; w < nstr * MCX_BLOOM_WORDS; w += K1_THREADS) {
+    for (uint32_t w = tid; w < nstr * 64u; w += K1_THREADS) {
         /* strings read in place get a full set: their patterns are not screened */
-        uint32_t v = use_lds ? 0u : 0xFFFFFFFFu;
-        if ((w & (MCX_BLOOM_WORDS - 1u)) == (MCX_BLOOM_FREE >> 5))
-            v |= 1u << (MCX_BLOOM_FREE & 31u);
-        bloom[w / MCX_BLOOM_WORDS][w & (MCX_BLOOM_WORDS - 1u)] = v;
+        uint32_t v = use_lds ? 0u : 0x01010101u;
+        if ((w & 63u) == (MCX_BLOOM_FREE >> 2))
+            v |= 1u << (8u * (MCX_BLOOM_FREE & 3u));
+        ((uint32_t *)bloom[w >> 6])[w & 63u] = v;
     }
     if (tid == 0) {
         nhits = 0;
@@ -349,8 +348,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             const uint32_t len = str_len[slot];
             LdsStr str{(lds_words_t)str_w, str_at[slot]};
             for (uint32_t q = lane; q + 4u <= len; q += 64u) {
-                uint32_t bit = mcx_gram_bit(str.word(q));
-                atomicOr(&bloom[slot][bit >> 5], 1u << (bit & 31u));
+                bloom[slot][mcx_gram_bit(str.word(q))] = 1u; /* every writer stores the same byte */
             }
             /* occurrence table, for strings the bit-parallel matcher takes */
             if (len <= MCX_OCC_MAX_LEN && lane < len)
@@ -641,11 +639,15 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             load_sigs(nk0, nn, nxt);
         }
         if (u < nunits) {
-            LdsBloom bl{(lds_words_t)bloom[slot]};
+            const uint8_t *bl = bloom[slot];
             bool pass[4];
 #pragma unroll
-            for (uint32_t jj = 0; jj < 4; ++jj)
-                pass[jj] = (4u * lane + jj < n) && mcx_sig_pass(cur.v[jj], bl);
+            for (uint32_t jj = 0; jj < 4; ++jj) {
+                /* the four bits the signature names, read together */
+                const uint32_t sg = cur.v[jj];
+                const uint32_t all = bl[sg & 0xFFu] & bl[(sg >> 8) & 0xFFu] & bl[(sg >> 16) & 0xFFu] & bl[sg >> 24];
+                pass[jj] = (4u * lane + jj < n) && all != 0u;
+            }
             /* one reservation per wave; the order of the survivors in the ring
              * does not matter, so every one of the four pattern columns is
              * compacted by its own ballot */
