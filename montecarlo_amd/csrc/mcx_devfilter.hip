@@ -16,7 +16,7 @@
  *   scan          counts -> kept_off
  *   dv_host<1>    one wave per host: source index and length of every kept string
  *   scan          lengths -> s_off_out
- *   dv_copy       16 lanes per kept string: the bytes
+ *   dv_copy_*     16 lanes per kept string: the bytes, whole words where the arenas are aligned
  */
 #include <string.h>
 
@@ -149,10 +149,10 @@ dv_host(const uint32_t *__restrict__ dev_off, uint32_t H, uint32_t max_per_host,
         cnt[h] = (max_per_host && running > max_per_host) ? max_per_host : running;
 }
 
-/* 16 lanes per kept string */
+/* 16 lanes per kept string, byte by byte: arenas that are not 4-byte aligned */
 __global__ void __launch_bounds__(FL_THREADS)
-dv_copy(const char *__restrict__ S, const uint32_t *__restrict__ s_off, const uint32_t *__restrict__ src,
-        const uint32_t *__restrict__ s_off_out, uint32_t K, char *__restrict__ S_out)
+dv_copy_bytes(const char *__restrict__ S, const uint32_t *__restrict__ s_off, const uint32_t *__restrict__ src,
+              const uint32_t *__restrict__ s_off_out, uint32_t K, char *__restrict__ S_out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t k = t >> 4, sub = t & 15u;
@@ -161,6 +161,79 @@ dv_copy(const char *__restrict__ S, const uint32_t *__restrict__ s_off, const ui
     const uint32_t from = s_off[src[k]], to = s_off_out[k], n = s_off_out[k + 1] - to;
     for (uint32_t b = sub; b < n; b += 16u)
         S_out[to + b] = S[from + b];
+}
+
+/*
+ * 16 lanes per group of DV_BATCH kept strings, a destination word per lane and
+ * string: the bytes in front of a string's first aligned destination word and
+ * behind its last one go one by one, every word in between is put together
+ * from the two aligned source words it straddles.  The index loads of the
+ * batch are issued together, then its source words, then its stores, so that
+ * a wave has DV_BATCH x 64 words in flight instead of 64.  Both arenas 4-byte
+ * aligned; s_off[N] bounds the source reads.
+ */
+#define DV_BATCH 4u
+__global__ void __launch_bounds__(FL_THREADS)
+dv_copy_words(const uint32_t *__restrict__ Sw, uint32_t N, const uint32_t *__restrict__ s_off,
+              const uint32_t *__restrict__ src, const uint32_t *__restrict__ s_off_out, uint32_t K,
+              char *__restrict__ S_out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k0 = (t >> 4) * DV_BATCH, sub = t & 15u;
+    if (k0 >= K)
+        return;
+    const char *S = (const char *)Sw;
+    const uint32_t src_bytes = s_off[N];
+    /* source word i; the arena's last, partly filled word is read byte by byte */
+    auto word = [&](uint32_t i) __attribute__((always_inline)) {
+        if (4u * i + 4u <= src_bytes)
+            return Sw[i];
+        uint32_t v = 0;
+        for (uint32_t b = 4u * i; b < src_bytes; ++b)
+            v |= (uint32_t)(uint8_t)S[b] << (8u * (b & 3u));
+        return v;
+    };
+    uint32_t si[DV_BATCH], from[DV_BATCH], to[DV_BATCH], n[DV_BATCH];
+#pragma unroll
+    for (uint32_t q = 0; q < DV_BATCH; ++q)
+        si[q] = k0 + q < K ? src[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < DV_BATCH; ++q) {
+        from[q] = s_off[si[q]];
+        to[q] = s_off_out[min(k0 + q, K)];
+        n[q] = k0 + q < K ? s_off_out[k0 + q + 1u] - to[q] : 0u;
+    }
+    uint32_t head[DV_BATCH], nwords[DV_BATCH], lo[DV_BATCH], hi[DV_BATCH];
+    uint8_t hb[DV_BATCH], tb[DV_BATCH];
+#pragma unroll
+    for (uint32_t q = 0; q < DV_BATCH; ++q) {
+        head[q] = min(n[q], (4u - (to[q] & 3u)) & 3u); /* bytes up to the first aligned destination word */
+        nwords[q] = (n[q] - head[q]) >> 2;
+        const uint32_t tail0 = head[q] + 4u * nwords[q];
+        hb[q] = sub < head[q] ? (uint8_t)S[from[q] + sub] : (uint8_t)0;
+        tb[q] = sub < n[q] - tail0 ? (uint8_t)S[from[q] + tail0 + sub] : (uint8_t)0;
+        const uint32_t at = from[q] + head[q] + 4u * sub;
+        lo[q] = sub < nwords[q] ? word(at >> 2) : 0u;
+        hi[q] = (sub < nwords[q] && (at & 3u)) ? word((at >> 2) + 1u) : 0u;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < DV_BATCH; ++q) {
+        const uint32_t tail0 = head[q] + 4u * nwords[q];
+        if (sub < head[q])
+            S_out[to[q] + sub] = (char)hb[q];
+        if (sub < n[q] - tail0)
+            S_out[to[q] + tail0 + sub] = (char)tb[q];
+        const uint32_t a = from[q] + head[q]; /* source byte of destination word 0 */
+        uint32_t *dst = (uint32_t *)(S_out + to[q] + head[q]);
+        if (sub < nwords[q])
+            dst[sub] = __builtin_amdgcn_alignbit(hi[q], lo[q], ((a + 4u * sub) & 3u) * 8u);
+        /* strings of more than 16 words: the rest, 16 words a step */
+        for (uint32_t w = sub + 16u; w < nwords[q]; w += 16u) {
+            const uint32_t at = a + 4u * w, i = at >> 2;
+            const uint32_t l2 = word(i), h2 = (at & 3u) ? word(i + 1u) : 0u;
+            dst[w] = __builtin_amdgcn_alignbit(h2, l2, (at & 3u) * 8u);
+        }
+    }
 }
 
 extern "C" {
@@ -265,8 +338,14 @@ int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, 
     mcx_scan_enqueue(ctx->stream, len, K, d_bsum, d_total, (uint32_t *)d_s_off_out);
     if (d_S_out && d_S) {
         const uint64_t threads = (uint64_t)K * 16u;
-        dv_copy<<<(uint32_t)((threads + FL_THREADS - 1) / FL_THREADS), FL_THREADS, 0, ctx->stream>>>(
-            (const char *)d_S, (const uint32_t *)d_s_off, src, (const uint32_t *)d_s_off_out, K, (char *)d_S_out);
+        const uint32_t blocks = (uint32_t)((threads + FL_THREADS - 1) / FL_THREADS);
+        if ((((uintptr_t)d_S | (uintptr_t)d_S_out) & 3u) == 0u)
+            dv_copy_words<<<(blocks + DV_BATCH - 1u) / DV_BATCH, FL_THREADS, 0, ctx->stream>>>((const uint32_t *)d_S, N,
+                                                                  (const uint32_t *)d_s_off, src,
+                                                                  (const uint32_t *)d_s_off_out, K, (char *)d_S_out);
+        else
+            dv_copy_bytes<<<blocks, FL_THREADS, 0, ctx->stream>>>((const char *)d_S, (const uint32_t *)d_s_off, src,
+                                                                  (const uint32_t *)d_s_off_out, K, (char *)d_S_out);
     }
     HIPCHK(ctx, hipGetLastError());
     if (bytes_out) {

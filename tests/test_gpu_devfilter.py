@@ -152,3 +152,34 @@ def test_replaced_tables_reach_the_device(gpu_ctx):
         m.tables_reset()
     v, _ = gpu_ctx.device_filter(rec, arena, off, one_host)
     assert (v & 1).tolist() == [0, 1, 1]
+
+
+@pytest.mark.parametrize("shift_in,shift_out", [(0, 0), (1, 0), (0, 2), (3, 1)])
+def test_compact_arena_alignment(gpu_ctx, oracle_mod, shift_in, shift_out):
+    """word-wide packing when both arenas are 4-byte aligned, byte-wide otherwise; strings of every
+    length from 0 to 40 at every offset, so heads, tails and straddled words all occur"""
+    rng = np.random.default_rng(5)
+    strings = [bytes(rng.integers(33, 127, size=int(n), dtype=np.uint8)) for n in rng.integers(0, 41, size=3000)]
+    S, s_off = pack_strings(strings)
+    N, H = len(strings), 30
+    rec = np.zeros(N, dtype=b.DEV_REC)
+    rec["subsystem"] = np.where(rng.random(N) < 0.6, b.SUB_HID, b.SUB_OTHER)      # listed / not listed
+    rec["driver"] = b.DRV_NONE
+    dev_off = np.linspace(0, N, H + 1).astype(np.uint32)
+    ctx = gpu_ctx
+    d_rec, d_dev, d_soff = ctx.to_device(rec), ctx.to_device(dev_off), ctx.to_device(s_off)
+    d_Sbuf = ctx.alloc(len(S) + 8)
+    ctx.lib.mcx_h2d(ctx.h, d_Sbuf.ptr + shift_in, S.ctypes.data, len(S))
+    d_v, d_kept = ctx.alloc(N), ctx.alloc(4 * (H + 1))
+    K = ctx.device_filter_dev(d_rec.ptr, N, None, None, 0, d_dev.ptr, H, 0, d_v.ptr, d_kept.ptr)
+    keep = np.nonzero(rec["subsystem"] == b.SUB_HID)[0]
+    assert K == len(keep)
+    d_out, d_soff2 = ctx.alloc(len(S) + 8), ctx.alloc(4 * (K + 1))
+    nbytes = ctx.fleet_compact_dev(d_v.ptr, d_Sbuf.ptr + shift_in, d_soff.ptr, N, d_dev.ptr, H, d_kept.ptr, K,
+                                   d_out.ptr + shift_out, d_soff2.ptr)
+    want = b"".join(strings[i] for i in keep)
+    assert nbytes == len(want)
+    got = d_out.download(np.uint8, len(S) + 8)[shift_out:shift_out + nbytes].tobytes()
+    assert got == want
+    for buf in (d_rec, d_dev, d_soff, d_Sbuf, d_v, d_kept, d_out, d_soff2):
+        buf.free()
