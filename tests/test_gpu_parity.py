@@ -196,6 +196,36 @@ def test_k1_properties_large(gpu_ctx, oracle_mod):
         b.free()
 
 
+def test_k1_full_table_and_its_shards(gpu_ctx, oracle_mod):
+    """configs[3]'s table (3 000 000 patterns) on one GPU, 70 000 strings: the whole table and
+    eight contiguous shards of it combined by the rule of the multi-GPU path (smallest shifted
+    first index, summed counts) give the same answers; a sample of strings against glibc."""
+    from montecarlo_amd.shard import shard_range
+
+    seed, P, N, G = 4, 3_000_000, 70_000, 8
+    A, a_off, a_mod = synth.alias_table(seed, P)
+    S, s_off = synth.modalias_strings(seed, P, N)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    first, count = gpu_ctx.alias_match(S, s_off)
+    assert (count > 0).mean() > 0.69 and ((first == NO_MATCH) == (count == 0)).all()
+    best = np.full(N, NO_MATCH, dtype=np.uint64)
+    total = np.zeros(N, dtype=np.uint64)
+    for r in range(G):
+        j0, j1 = shard_range(P, r, G)
+        base = int(a_off[j0])
+        gpu_ctx.alias_table_load(A[base:int(a_off[j1])], a_off[j0:j1 + 1] - np.uint32(base), a_mod[j0:j1])
+        f, c = gpu_ctx.alias_match(S, s_off)
+        shifted = np.where(f == NO_MATCH, np.uint64(NO_MATCH), f.astype(np.uint64) + np.uint64(j0))
+        best = np.minimum(best, shifted)
+        total += c
+    assert np.array_equal(best.astype(np.uint32), first)
+    assert np.array_equal(total.astype(np.uint32), count)
+    sample = list(range(0, N, N // 10))
+    Ss, ss_off = pack_strings([S[s_off[i]:s_off[i + 1]].tobytes() for i in sample])
+    o_first, o_count = oracle_mod.alias_match(A, a_off, Ss, ss_off)
+    assert np.array_equal(first[sample], o_first) and np.array_equal(count[sample], o_count)
+
+
 def test_k1_hw_flags(gpu_ctx):
     pats = [b"pci:v*", b"acpi*:PNP0C09:*", b"usb:v1*", b"input:b*", b" of:N*", b"xpci:v", b"serio:ty*", b"hid:b*",
             b"platform:x"]
