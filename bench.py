@@ -258,10 +258,10 @@ def main():
         }
 
     if rank == 0 and not args.no_k2:
-        out["k2"] = bench_k2(ctx, synth, args)
+        out["k2"] = bench_k2(ctx, synth, args, with_cpu=not args.no_cpu and world == 1)
     if rank == 0 and not args.no_fleet:
         out["fleet"] = bench_fleet(ctx, synth, args)
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and world == 1:
         import oracle
 
         n_chk = min(N, 64)
@@ -281,8 +281,9 @@ def main():
         print(json.dumps(out))
 
 
-def bench_k2(ctx, synth, args):
-    """configs[2]: flags and closure over the synthetic dependency DAG."""
+def bench_k2(ctx, synth, args, with_cpu=False):
+    """configs[2]: flags and closure over the synthetic dependency DAG; with_cpu adds the
+    oracle's single-threaded C passes over the same graph (the host-C side of the metric)."""
     V = args.graph_vertices
     rowptr, col = synth.dep_graph(3, V, args.graph_degree)
     E = len(col)
@@ -329,6 +330,36 @@ def bench_k2(ctx, synth, args):
         }
     for b in (d_in, d_seed, d_out, d_ref, d_clo):
         b.free()
+    if with_cpu:
+        import oracle
+
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or time.perf_counter() - t0 < 1.0:
+            oracle.dep_flags(rowptr, col, flags)
+            n += 1
+        cpu_flags_ms = (time.perf_counter() - t0) * 1e3 / n
+        cpu = {"cores": 1, "kind": "port",
+               "sample": f"{n} whole passes of the same graph, edge scan + queue BFS in C, one thread",
+               "dep_flags": {"ms": cpu_flags_ms, "edges_per_s": E / (cpu_flags_ms / 1e3)}}
+        # holders of every module, built once and not timed (the GPU side builds its own at graph
+        # load): the holders-direction search is then a forward search over this graph
+        src = np.repeat(np.arange(V, dtype=np.uint32), np.diff(rowptr.astype(np.int64)))
+        order = np.argsort(col, kind="stable")
+        rcol = np.ascontiguousarray(src[order])
+        rrow = np.zeros(V + 1, dtype=np.uint32)
+        rrow[1:] = np.cumsum(np.bincount(col, minlength=V), dtype=np.uint64).astype(np.uint32)
+        for name, graph in (("closure_holders", (rrow, rcol)), ("closure_deps", (rowptr, col))):
+            t0 = time.perf_counter()
+            n = 0
+            while n < 3 or time.perf_counter() - t0 < 0.5:
+                _, o_edges, _ = oracle.dep_closure(graph[0], graph[1], flags, seeds, 1)
+                n += 1
+            ms = (time.perf_counter() - t0) * 1e3 / n
+            if o_edges != res[name]["edges_scanned"]:
+                raise SystemExit("bench: closure differs from the oracle")
+            cpu[name] = {"ms": ms, "edges_per_s": o_edges / (ms / 1e3) if ms > 0 else 0.0}
+        res["cpu_baseline"] = cpu
     return res
 
 

@@ -164,6 +164,8 @@ k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__
  * the 160 KB of one workgroup.
  */
 #define K2L_THREADS 1024
+#define K2L_ROWS_CAP 4096u /* rows of one slice, at most */
+#define K2L_ROWS_PER_THREAD (K2L_ROWS_CAP / K2L_THREADS)
 __global__ void __launch_bounds__(K2L_THREADS)
 k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ rcol,
              const uint32_t *__restrict__ cu_part, const uint8_t *__restrict__ in_flags,
@@ -171,27 +173,22 @@ k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ 
              uint8_t *__restrict__ out_flags, uint32_t *__restrict__ refcnt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t k2_lds[];
-    uint32_t *bm = k2_lds;              /* W words */
-    uint32_t *rp = bm + W;              /* rows_max + 1 */
+    const uint32_t W4 = (W + 3u) & ~3u;
+    uint32_t *bm = k2_lds;              /* W words, rounded up to whole 16-byte pieces */
+    uint32_t *rp = bm + W4;             /* rows_max + 1 */
     uint32_t *ebits = rp + rows_max + 1u; /* edges_max / 32 + 2 */
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t r0 = cu_part[blockIdx.x], r1 = cu_part[blockIdx.x + 1];
     const uint32_t R = r1 - r0;
-    for (uint32_t i = tid; i < W; i += K2L_THREADS)
-        bm[i] = loaded_bm[i];
-    for (uint32_t i = tid; i <= R; i += K2L_THREADS)
-        rp[i] = rrowptr[r0 + i];
-    __syncthreads();
-    const uint32_t e0 = rp[0], ne = rp[R] - e0;
+    const uint32_t e0 = rrowptr[r0], ne = rrowptr[r1] - e0;
     /* a wave takes 1024 consecutive edges per step, 16 per lane, read with four
      * 16-byte loads that are all in flight before the first answer is looked
      * up: enough bytes under way per CU to cover the memory latency.  A lane's
-     * 16 answers are one half-word of the edge-bit array. */
-    uint16_t *ebits16 = (uint16_t *)ebits;
+     * 16 answers are one half-word of the edge-bit array.  The loads of the
+     * first step are issued before the bitmap is copied, so that the two
+     * latencies overlap. */
     const uint32_t wave = tid >> 6;
-    for (uint32_t base = wave * 1024u; base < ne; base += (K2L_THREADS / 64u) * 1024u) {
-        const uint32_t first = base + 16u * lane;
-        uint32_t u[16];
+    auto load_edges = [&](uint32_t first, uint32_t (&u)[16]) __attribute__((always_inline)) {
         if (first + 16u <= ne) {
             const uint4 *src = (const uint4 *)(rcol + e0 + first); /* 4-byte aligned */
 #pragma unroll
@@ -207,6 +204,28 @@ k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ 
             for (uint32_t k = 0; k < 16u; ++k)
                 u[k] = first + k < ne ? rcol[e0 + first + k] : 0xFFFFFFFFu;
         }
+    };
+    uint32_t u[16];
+    load_edges(wave * 1024u + 16u * lane, u);
+    /* the flag bytes of this thread's rows (at most K2L_ROWS_PER_THREAD of them) */
+    uint32_t fl[K2L_ROWS_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < K2L_ROWS_PER_THREAD; ++k)
+        fl[k] = tid + K2L_THREADS * k < R ? in_flags[r0 + tid + K2L_THREADS * k] : 0u;
+    /* loaded_bm holds at least W4 words (it is V words long) */
+    for (uint32_t i = tid; 4u * i < W4; i += K2L_THREADS)
+        ((uint4 *)bm)[i] = ((const uint4 *)loaded_bm)[i];
+    for (uint32_t i = tid; i <= R; i += K2L_THREADS)
+        rp[i] = rrowptr[r0 + i];
+    __syncthreads();
+    uint16_t *ebits16 = (uint16_t *)ebits;
+    for (uint32_t base = wave * 1024u; base < ne; base += (K2L_THREADS / 64u) * 1024u) {
+        const uint32_t first = base + 16u * lane;
+        /* the next step's edges are requested before this step's are looked up */
+        const bool more = base + (K2L_THREADS / 64u) * 1024u < ne;
+        uint32_t un[16];
+        if (more)
+            load_edges(first + (K2L_THREADS / 64u) * 1024u, un);
         uint32_t bits = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 16u; ++k) {
@@ -216,9 +235,18 @@ k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ 
         }
         if (first < ne + 16u)
             ebits16[first >> 4] = (uint16_t)bits;
+        if (more) {
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k)
+                u[k] = un[k];
+        }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < R; i += K2L_THREADS) {
+#pragma unroll
+    for (uint32_t k = 0; k < K2L_ROWS_PER_THREAD; ++k) {
+        const uint32_t i = tid + K2L_THREADS * k;
+        if (i >= R)
+            break;
         const uint32_t a = rp[i] - e0, b = rp[i + 1u] - e0;
         uint32_t h = 0;
         for (uint32_t w = a >> 5; 32u * w < b; ++w) {
@@ -230,7 +258,7 @@ k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ 
             h += (uint32_t)__popc(bits);
         }
         const uint32_t v = r0 + i;
-        const uint32_t f = in_flags[v];
+        const uint32_t f = fl[k];
         uint32_t o = 0;
         if (f & MCX_F_LOADED) {
             if (h)
@@ -621,7 +649,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n_cu <= 0)
             n_cu = 256;
         const uint64_t target = (uint64_t)E / (uint64_t)n_cu + 1;
-        const uint32_t rows_cap = 4096; /* 16 KB of row pointers per slice */
+        const uint32_t rows_cap = K2L_ROWS_CAP; /* 16 KB of row pointers per slice */
         cu_part.push_back(0);
         for (uint32_t r = 0; r < V;) {
             uint32_t end = r;
@@ -636,7 +664,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
             cu_part.push_back(end);
             r = end;
         }
-        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 4);
+        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 8);
         if (V == 0 || lds > 160 * 1024 - 512)
             cu_part.clear(); /* does not fit one workgroup: the row-block variant is used */
     }
@@ -668,7 +696,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         mcx_free_graph(ctx);
         return rc;
     }
-    size_t vb = 4 * ((size_t)V ? V : 1);
+    size_t vb = 4 * ((size_t)V > 4 ? V : 4); /* the bitmap copy of K2a reads whole 16-byte pieces */
     if (hipMalloc((void **)&ctx->d_queue[0], vb) != hipSuccess ||
         hipMalloc((void **)&ctx->d_queue[1], vb) != hipSuccess ||
         hipMalloc((void **)&ctx->d_bfs, 4 * ((size_t)K2B_STATE_WORDS + 2 * (size_t)hub_cap + 2 * (size_t)W + 1)) !=
@@ -692,7 +720,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     ctx->cu_rows_max = cu_rows_max;
     ctx->cu_edges_max = cu_edges_max;
     if (ctx->n_cu_part) {
-        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 4);
+        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 8);
         hipError_t ea = hipFuncSetAttribute((const void *)k2_flags_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds);
         if (ea != hipSuccess)
@@ -718,7 +746,7 @@ int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, v
         (const uint8_t *)d_in_flags, ctx->V, ((uintptr_t)d_in_flags & 15u) == 0u ? 1u : 0u, bm);
     if (ctx->n_cu_part) {
         const uint32_t W = (ctx->V + 31u) / 32u;
-        const size_t lds = 4 * ((size_t)W + ctx->cu_rows_max + 1 + ctx->cu_edges_max / 32 + 4);
+        const size_t lds = 4 * ((size_t)W + ctx->cu_rows_max + 1 + ctx->cu_edges_max / 32 + 8);
         k2_flags_lds<<<ctx->n_cu_part, K2L_THREADS, lds, ctx->stream>>>(
             ctx->d_rrowptr, ctx->d_rcol, ctx->d_cu_part, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
             (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
