@@ -332,6 +332,19 @@ int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, 
                           uint32_t kept_total, void *d_S_out, void *d_s_off_out, void *d_src,
                           uint64_t *bytes_out);
 
+/*
+ * The whole of configs "inventory -> module lists" in one call, device buffers:
+ * mcx_device_filter_dev (verdicts are left in d_verdict), the packing of the
+ * listed devices' strings, and mcx_fleet_roots_dev over them; arguments as
+ * in those three.  Allocates and frees the packed strings itself.
+ */
+int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
+                                  uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                                  const void *d_dev_off, uint32_t H, uint32_t max_per_host,
+                                  const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                                  const void *d_safe_name, void *d_verdict,
+                                  void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out);
+
 /* ---- the library's name tables as data ------------------------------------ */
 
 /*

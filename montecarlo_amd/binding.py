@@ -154,6 +154,11 @@ def load_library():
             [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, _vp,
              ctypes.POINTER(ctypes.c_uint64)],
         ),
+        "mcx_fleet_inventory_roots_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, ctypes.c_uint32,
+             _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
+        ),
         "mcx_fleet_roots_dev": (
             ctypes.c_int,
             [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp,
@@ -465,6 +470,20 @@ class Context:
             "mcx_fleet_compact_dev",
         )
         return nbytes.value if want_bytes else None
+
+
+    def fleet_inventory_roots_dev(self, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, d_dev_off, H,
+                                  max_per_host, d_extra_off, d_extra_ids, X, d_safe, d_verdict, d_root_off,
+                                  d_root_ids, cap, size_only=False):
+        """records -> per-host module lists; returns the total (see fleet_roots_dev)"""
+        total = ctypes.c_uint64()
+        rc = self.lib.mcx_fleet_inventory_roots_dev(self.h, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D,
+                                                    d_dev_off, H, int(max_per_host), d_extra_off, d_extra_ids, X,
+                                                    d_safe, d_verdict, d_root_off, d_root_ids, cap,
+                                                    ctypes.byref(total))
+        if not (size_only and rc == -6 and cap < total.value < 2**32):
+            self._check(rc, "mcx_fleet_inventory_roots_dev")
+        return total.value
 
 
 def safe_module_names(names):

@@ -357,6 +357,45 @@ int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, 
     return MCX_OK;
 }
 
+int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
+                                  uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                                  const void *d_dev_off, uint32_t H, uint32_t max_per_host,
+                                  const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                                  const void *d_safe_name, void *d_verdict, void *d_root_off, void *d_root_ids,
+                                  uint64_t cap, uint64_t *total_out)
+{
+    if (!ctx || !d_s_off || !d_dev_off || !d_root_off || !total_out || (N && !d_verdict))
+        return MCX_E_BAD_ARG;
+    if (!ctx->table_loaded || !ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    *total_out = 0;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    /* the listed devices' strings live in a buffer of this call: the stages
+     * share the context's scratch, which may move when it grows */
+    uint32_t s_bytes = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&s_bytes, (const uint32_t *)d_s_off + N, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t o_soff = up256(s_bytes ? s_bytes : 1), o_kept = o_soff + up256(4 * ((size_t)N + 1));
+    char *tmp = nullptr;
+    if (hipMalloc((void **)&tmp, o_kept + up256(4 * ((size_t)H + 1))) != hipSuccess) {
+        ctx->err = "hipMalloc of the packed strings failed";
+        return MCX_E_NOMEM;
+    }
+    uint64_t kept = 0;
+    int rc = mcx_device_filter_dev(ctx, d_rec, N, d_drv_arena, d_drv_off, D, d_dev_off, H, max_per_host, d_verdict,
+                                   tmp + o_kept, &kept);
+    if (rc == MCX_OK)
+        rc = mcx_fleet_compact_dev(ctx, d_verdict, d_S, d_s_off, N, d_dev_off, H, tmp + o_kept, (uint32_t)kept, tmp,
+                                   tmp + o_soff, nullptr, nullptr);
+    if (rc == MCX_OK)
+        rc = mcx_fleet_roots_dev(ctx, tmp, tmp + o_soff, (uint32_t)kept, tmp + o_kept, H, d_extra_off, d_extra_ids, X,
+                                 d_safe_name, d_root_off, d_root_ids, cap, total_out);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
 int mcx_device_filter(mcx_ctx *ctx, const mcx_dev_rec_t *rec, uint32_t N, const char *drv_arena,
                       const uint32_t *drv_off, uint32_t D, const uint32_t *dev_off, uint32_t H,
                       uint32_t max_per_host, uint8_t *verdict, uint32_t *kept_off)

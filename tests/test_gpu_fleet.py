@@ -153,3 +153,38 @@ def test_fleet_full_size_tiled(gpu_ctx, oracle_mod):
     want_off = np.concatenate([[0], (w_off[1:].astype(np.uint64)[None, :] +
                                      (np.arange(reps, dtype=np.uint64) * T)[:, None]).ravel()]).astype(np.uint32)
     assert np.array_equal(off, want_off)
+
+
+@pytest.mark.parametrize("cap_per_host", [0, 5])
+def test_inventory_to_lists_in_one_call(gpu_ctx, oracle_mod, cap_per_host):
+    """device records -> device list -> alias match -> module lists, one call, against the
+    oracle's device filter followed by the oracle's per-host loop over the listed devices"""
+    f = make_fleet(61, 3000, 300, 14, 4)
+    ctx, N, H = gpu_ctx, f["N"], f["H"]
+    rec = synth.device_records(61, f["S"], f["s_off"])
+    arena, off = synth.driver_names_packed()
+    ctx.alias_table_load(f["A"], f["a_off"], f["a_mod"])
+    ctx.dep_graph_load(f["rowptr"], f["col"])
+    # expectation
+    o_v, o_kept = oracle_mod.device_filter(rec, arena, off, f["dev_off"], cap_per_host)
+    keep = np.nonzero(o_v & 1)[0]
+    raw = f["S"].tobytes()
+    Sk, sk_off = pack_strings([raw[f["s_off"][i]:f["s_off"][i + 1]] for i in keep])
+    g = dict(f, S=Sk, s_off=sk_off, dev_off=o_kept, N=len(keep))
+    w_off, w_ids = oracle_fleet(oracle_mod, ctx, g)
+    # one call
+    bufs = [ctx.to_device(x) for x in (rec, f["S"], f["s_off"], arena, off, f["dev_off"], f["extra_off"],
+                                       f["extra_ids"], f["safe"])]
+    d_rec, d_S, d_soff, d_arena, d_doff, d_dev, d_xoff, d_xid, d_safe = bufs
+    d_v, d_roff = ctx.alloc(N), ctx.alloc(4 * (H + 1))
+    args = (d_rec.ptr, d_S.ptr, d_soff.ptr, N, d_arena.ptr, d_doff.ptr, len(off) - 1, d_dev.ptr, H, cap_per_host,
+            d_xoff.ptr, d_xid.ptr, len(f["extra_ids"]), d_safe.ptr, d_v.ptr, d_roff.ptr)
+    total = ctx.fleet_inventory_roots_dev(*args, None, 0, size_only=True)
+    assert total == len(w_ids) and total > 0
+    d_rid = ctx.alloc(4 * total)
+    assert ctx.fleet_inventory_roots_dev(*args, d_rid.ptr, total) == total
+    assert np.array_equal(d_v.download(np.uint8, N) & 3, o_v)
+    assert np.array_equal(d_roff.download(np.uint32, H + 1), w_off)
+    assert np.array_equal(d_rid.download(np.uint32, total), w_ids)
+    for buf in bufs + [d_v, d_roff, d_rid]:
+        buf.free()
