@@ -1,8 +1,7 @@
-#!/usr/bin/env python3
 """Benchmark of the batch hot path on MI355X.
 
 One step = one pass of the alias matcher (K1) over one batch of synthetic
-modalias strings that are already resident in HBM: BASELINE.json configs[1],
+modalias strings that are already resident in HBM: configs[1] of the benchmark definition,
 1000 strings x 30000 alias patterns, seed 2.  With --gpus N (launched through
 torch.distributed.run, one rank per GPU) every rank matches its own 1000-string
 shard of a 1000*N batch against its own copy of the table: the path shards by
@@ -168,7 +167,7 @@ def main():
     from montecarlo_amd import shard
 
     if by_pattern:
-        # BASELINE configs[3] layout: rank r holds table slice [j0, j1) and sees all N strings
+        # configs[3] layout: rank r holds table slice [j0, j1) and sees all N strings
         j0, j1 = shard.shard_range(P, rank, world)
         A, a_off, a_mod = synth.alias_table(args.seed, P, j0, j1)
         S, s_off = synth.modalias_strings(args.seed, P, N)

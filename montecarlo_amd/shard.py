@@ -4,7 +4,7 @@ Two ways to cut the work, both exact:
 
 * by string (the default): every rank holds the whole alias table and matches its
   own slice of the batch.  Nothing is exchanged on the data path.
-* by pattern (BASELINE configs[3], "alias table sharded across 2/4/8 GPUs"): every
+* by pattern (configs[3] of the benchmark definition, "alias table sharded across 2/4/8 GPUs"): every
   rank holds a contiguous slice [j0, j1) of the table and matches all strings
   against it.  A string's global first match is the smallest of the per-rank
   first matches (shifted by j0) and its match count is the sum of the per-rank

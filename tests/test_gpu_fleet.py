@@ -126,7 +126,7 @@ def test_fleet_medium_vs_oracle(gpu_ctx, oracle_mod):
 
 
 def test_fleet_full_size_tiled(gpu_ctx, oracle_mod):
-    """BASELINE-sized fleet (100000 hosts, ~100 devices each, 30000 patterns): the
+    """full-size fleet of the benchmark definition (100000 hosts, ~100 devices each, 30000 patterns): the
     fleet is 100 copies of 1000 distinct hosts, so the expected lists are the
     oracle's lists of those 1000 hosts, repeated"""
     base = make_fleet(51, 30000, 1000, 100, 8)

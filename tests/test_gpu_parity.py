@@ -1,5 +1,5 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
-seeded inputs, against the committed golden vectors, and - at full BASELINE sizes -
+seeded inputs, against the committed golden vectors, and - at the full sizes of the benchmark definition -
 through size-independent properties.  Bit-exact: everything here is integer work."""
 import json
 import os
