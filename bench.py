@@ -259,7 +259,7 @@ def main():
     if rank == 0 and not args.no_k2:
         out["k2"] = bench_k2(ctx, synth, args, with_cpu=not args.no_cpu and world == 1)
     if rank == 0 and not args.no_fleet:
-        out["fleet"] = bench_fleet(ctx, synth, args)
+        out["fleet"] = bench_fleet(ctx, synth, args, with_cpu=not args.no_cpu and world == 1)
     if rank == 0 and not args.no_cpu and world == 1:
         import oracle
 
@@ -362,9 +362,10 @@ def bench_k2(ctx, synth, args, with_cpu=False):
     return res
 
 
-def bench_fleet(ctx, synth, args):
+def bench_fleet(ctx, synth, args, with_cpu=False):
     """configs[4]: alias match -> used drivers -> loaded set -> holders -> root filter for a
-    whole fleet, inputs resident in HBM."""
+    whole fleet, inputs resident in HBM; with_cpu times the oracle on the first hosts of the
+    same fleet (alias part by the indexed CPU twin: the glibc loop would take minutes)."""
     from montecarlo_amd import safe_module_names
 
     H, P, seed = args.fleet_hosts, args.patterns, 5
@@ -422,11 +423,35 @@ def bench_fleet(ctx, synth, args):
         ctx.fleet_compact_dev(d_v.ptr, d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_kept.ptr, K, d_S2.ptr, d_soff2.ptr,
                               None, want_bytes=False)
     compact_ms = ctx.timer_end() / reps
+    cpu = None
+    if with_cpu:
+        import oracle
+
+        Hs = min(H, 500)
+        Ns = int(dev_off[Hs])
+        hw = ctx.alias_hw_flags(V)
+        t0 = time.perf_counter()
+        f_s, _ = oracle.alias_match(A, a_off, S[: s_off[Ns]], s_off[: Ns + 1], use_twin=True)
+        drv = np.where(f_s != 0xFFFFFFFF, a_mod[np.minimum(f_s, len(a_mod) - 1)], 0xFFFFFFFF).astype(np.uint32)
+        o_off, o_ids = oracle.fleet_roots(rowptr, col, drv, dev_off[: Hs + 1], extra_off[: Hs + 1],
+                                          extra_ids[: int(extra_off[Hs])], safe, hw)
+        fleet_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Nr = min(N, 1_000_000)
+        Hr = int(np.searchsorted(dev_off, Nr, side="right")) - 1
+        oracle.device_filter(rec[: int(dev_off[Hr])], arena, off, dev_off[: Hr + 1], 64)
+        filt_s = time.perf_counter() - t0
+        cpu = {"cores": 1, "kind": "port",
+               "sample": f"first {Hs} hosts ({Ns} devices) through the per-host loop, alias part by the indexed "
+                         f"twin; device list predicates over the first {int(dev_off[Hr])} records",
+               "fleet_hosts_per_s": Hs / fleet_s, "fleet_devices_per_s": Ns / fleet_s,
+               "device_filter_records_per_s": int(dev_off[Hr]) / filt_s}
     filter_bytes = 16 * N + 2 * N + 8 * (H + 1)
     compact_bytes = N + 4 * (N + 1) + 8 * (H + 1) + 2 * kept_bytes + 4 * (K + 1)
     for b in bufs[:3] + [d_rec, d_arena, d_off, d_v, d_kept, d_S2, d_soff2]:
         b.free()
     return {
+        **({"cpu_baseline": cpu} if cpu else {}),
         "device_filter": {
             "listed_devices": K,
             "filter_ms": filter_ms,
