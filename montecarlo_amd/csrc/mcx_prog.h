@@ -185,11 +185,10 @@ struct mcx_seg_t {
     uint32_t setlist, next;
 };
 
-template <class Prog>
-MCX_HD mcx_seg_t mcx_seg_at(const Prog &p, uint32_t w, uint32_t k, uint32_t hdr)
+/* from the segment's header word sh, read at word w */
+MCX_HD mcx_seg_t mcx_seg_from(uint32_t sh, uint32_t w, uint32_t k, uint32_t hdr)
 {
     mcx_seg_t g;
-    const uint32_t sh = p[w];
     const bool inl = (sh & MCX_SEG_INLINE) != 0u;
     g.nchars = inl ? ((sh >> 24) & 3u) : (sh & 0xFFFFu);
     g.nsets = inl ? 0u : ((sh >> 16) & 0x3FFFu);
@@ -206,8 +205,25 @@ MCX_HD mcx_seg_t mcx_seg_at(const Prog &p, uint32_t w, uint32_t k, uint32_t hdr)
     return g;
 }
 
+template <class Prog>
+MCX_HD mcx_seg_t mcx_seg_at(const Prog &p, uint32_t w, uint32_t k, uint32_t hdr)
+{
+    return mcx_seg_from(p[w], w, k, hdr);
+}
+
 /* value and mask of chunk c (c0 <= c; a chunk past the last one, read ahead and
  * never used, gets whatever lies there) */
+template <class Prog>
+MCX_HD uint32_t mcx_chunk_mask(const Prog &p, const mcx_seg_t &g, uint32_t c)
+{
+    const uint32_t r = c - g.c0;
+    const uint32_t mw = p[g.masks + (r >> 3)];
+    const uint32_t left = g.nchars > 4u * c ? g.nchars - 4u * c : 0u;
+    const uint32_t implied = left >= 4u ? 0xFFFFFFFFu : (left ? 0xFFFFFFFFu >> (8u * (4u - left)) : 0u);
+    const uint32_t stored = mcx_expand_mask(mw >> (4u * (r & 7u)));
+    return g.kind == 0u ? implied : (g.kind == 1u ? stored : g.inline_mask);
+}
+
 template <class Prog>
 MCX_HD void mcx_chunk(const Prog &p, const mcx_seg_t &g, uint32_t c, uint32_t &v, uint32_t &m)
 {
@@ -362,15 +378,27 @@ MCX_HD bool mcx_precheck(uint32_t hdr, uint32_t len)
 /* set of start positions at which segment g fits; chunks before g.c0 are the
  * index key's and count as fitting */
 template <class Prog, class Occ>
+MCX_HD uint64_t mcx_seg_mask_from(const Prog &p, const mcx_seg_t &g, uint32_t v, uint32_t m, const Occ &occ,
+                                  uint64_t all, const uint32_t *sets);
+
+template <class Prog, class Occ>
 MCX_HD uint64_t mcx_seg_mask(const Prog &p, const mcx_seg_t &g, const Occ &occ, uint64_t all, const uint32_t *sets)
+{
+    uint32_t v, m;
+    mcx_chunk(p, g, g.c0, v, m);
+    return mcx_seg_mask_from(p, g, v, m, occ, all, sets);
+}
+
+/* v, m: value and mask of the segment's first stored chunk (chunk g.c0) */
+template <class Prog, class Occ>
+MCX_HD uint64_t mcx_seg_mask_from(const Prog &p, const mcx_seg_t &g, uint32_t v, uint32_t m, const Occ &occ,
+                                  uint64_t all, const uint32_t *sets)
 {
     /* branch-free and one chunk ahead: the words of chunk c+1 are requested
      * before the four table reads of chunk c are combined (reads of a program
      * word or two past the segment, and of table entry 0 for padding bytes, are
      * harmless: their results are masked) */
     uint64_t M = all;
-    uint32_t v, m;
-    mcx_chunk(p, g, g.c0, v, m);
     for (uint32_t c = g.c0; c < g.nchunks; ++c) {
         uint32_t vn, mn;
         mcx_chunk(p, g, c + 1u, vn, mn);
@@ -484,11 +512,22 @@ MCX_HD bool mcx_slot_match_occ(const Prog &slot, const Occ &occ, uint32_t len, c
         return false;
     const uint64_t all = len >= 64u ? ~(uint64_t)0 : (((uint64_t)1 << len) - 1u);
     const uint32_t nseg = MCX_HDR_NSEG(hdr);
+    /* the whole directory first, then per segment its header word and the word
+     * behind it together (the first chunk's value unless the segment is its own
+     * value word): a caller reading the slot from far away waits once per
+     * segment instead of three times */
+    const uint32_t d0 = slot[MCX_SLOT_DIR], d1 = slot[MCX_SLOT_DIR + 1u], d2 = slot[MCX_SLOT_DIR + 2u],
+                   d3 = slot[MCX_SLOT_DIR + 3u];
     uint32_t state = MCX_STATE_START;
     for (uint32_t k = 0; k < nseg; ++k) {
-        const mcx_seg_t g = mcx_seg_at(slot, mcx_dir_word(slot, k), k, hdr);
-        state = mcx_step_apply(mcx_step_make(hdr, len, k, mcx_seg_mask(slot, g, occ, all, sets), g.nchars), len,
-                               state);
+        const uint32_t dw = (k >> 2) == 0u ? d0 : ((k >> 2) == 1u ? d1 : ((k >> 2) == 2u ? d2 : d3));
+        const uint32_t w = (dw >> (8u * (k & 3u))) & 0xFFu;
+        const uint32_t sh = slot[w], nx = slot[w + 1u];
+        const mcx_seg_t g = mcx_seg_from(sh, w, k, hdr);
+        const uint32_t v = g.kind == 2u ? sh : nx;
+        const uint32_t m = mcx_chunk_mask(slot, g, g.c0);
+        state = mcx_step_apply(mcx_step_make(hdr, len, k, mcx_seg_mask_from(slot, g, v, m, occ, all, sets), g.nchars),
+                               len, state);
     }
     return MCX_STATE_OK(state) != 0u;
 }
