@@ -524,10 +524,20 @@ MCX_HD bool mcx_slot_match_occ(const Prog &slot, const Occ &occ, uint32_t len, c
         const uint32_t w = (dw >> (8u * (k & 3u))) & 0xFFu;
         const uint32_t sh = slot[w], nx = slot[w + 1u];
         const mcx_seg_t g = mcx_seg_from(sh, w, k, hdr);
-        const uint32_t v = g.kind == 2u ? sh : nx;
-        const uint32_t m = mcx_chunk_mask(slot, g, g.c0);
-        state = mcx_step_apply(mcx_step_make(hdr, len, k, mcx_seg_mask_from(slot, g, v, m, occ, all, sets), g.nchars),
-                               len, state);
+        uint64_t M;
+        if (g.kind == 2u) {
+            /* most segments between two stars are one to three bytes and are
+             * their own value word: three table reads, nothing else to fetch */
+            const uint64_t o0 = occ[sh & 0xFFu], o1 = occ[(sh >> 8) & 0xFFu], o2 = occ[(sh >> 16) & 0xFFu];
+            const uint32_t im = g.inline_mask;
+            M = (im & 0xFFu) ? o0 : all;
+            M &= g.nchars > 1u ? (((im & 0xFF00u) ? o1 : all) >> 1) : ~(uint64_t)0;
+            M &= g.nchars > 2u ? (((im & 0xFF0000u) ? o2 : all) >> 2) : ~(uint64_t)0;
+        } else {
+            const uint32_t m = mcx_chunk_mask(slot, g, g.c0);
+            M = mcx_seg_mask_from(slot, g, nx, m, occ, all, sets);
+        }
+        state = mcx_step_apply(mcx_step_make(hdr, len, k, M, g.nchars), len, state);
     }
     return MCX_STATE_OK(state) != 0u;
 }
