@@ -183,3 +183,87 @@ def test_compact_arena_alignment(gpu_ctx, oracle_mod, shift_in, shift_out):
     assert got == want
     for buf in (d_rec, d_dev, d_soff, d_Sbuf, d_v, d_kept, d_out, d_soff2):
         buf.free()
+
+
+def numpy_listed(rec, names):
+    """the predicates once more, vectorised (no per-host limit): a third statement of
+    montecarlo/libmontecarlo.c:233-440, 729-823 beside the kernel and the C oracle"""
+    infra = np.array([n in ("pcieport", "pci_bridge", "pciehp", "pcie_aspm", "pcie_pme", "pcie_edr", "shpchp",
+                            "piix4_smbus") for n in names] + [False])
+    host = np.array([("hcd" in n) or n == "hub" for n in names] + [False])
+    drv = rec["driver"].astype(np.int64)
+    known = drv < len(names)
+    didx = np.where(known, drv, len(names))
+    sub, dt, at = rec["subsystem"], rec["devtype"], rec["attrs"]
+    cls = rec["pci_class"]
+    base, subc = (cls >> 16) & 0xFF, (cls >> 8) & 0xFF
+    pci_bad = ((at & b.DA_PCI_CLASS) != 0) & ((base == 6) | ((base == 0xC) & (subc == 5)) | (base == 8))
+    pci_bad |= (rec["driver"] == b.DRV_NOSLASH) | infra[didx]
+    scsi_bad = np.isin(dt, [b.DT_NONE, b.DT_SCSI_HOST, b.DT_SCSI_TARGET, b.DT_SCSI_GENERIC]) | \
+        ((at & (b.DA_SCSI_MODEL | b.DA_SCSI_VENDOR)) == 0)
+    usb_bad = (dt != b.DT_USB_INTERFACE) | (((at & b.DA_IFACE_CLASS) != 0) & (rec["iface_class"] == 9)) | \
+        ((at & b.DA_PARENT) == 0) | (((at & b.DA_PARENT_CLASS) != 0) & (rec["parent_class"] == 9)) | host[didx]
+    listed = np.where(sub == b.SUB_PCI, ~pci_bad, np.where(sub == b.SUB_SCSI, ~scsi_bad, np.where(
+        sub == b.SUB_USB, ~usb_bad, (sub == b.SUB_HID) | (sub == b.SUB_PCMCIA))))
+    excl = (((at & b.DA_OWN_CLASS) != 0) & (rec["own_class"] == 8)) | \
+        (((at & b.DA_IFACE_CLASS) != 0) & (rec["iface_class"] == 8)) | \
+        (((at & b.DA_PARENT) != 0) & ((at & b.DA_PARENT_CLASS) != 0) & (rec["parent_class"] == 8))
+    return listed, excl
+
+
+def test_filter_full_size_properties(gpu_ctx, oracle_mod):
+    """the fleet of the benchmark definition (10^5 hosts, 10^7 device records): verdicts against the
+    vectorised statement of the predicates, the per-host limit and the packed strings through
+    properties that hold at any size, a slice of hosts against the C oracle"""
+    H, P = 100_000, 30_000
+    dev_cnt, _, _ = synth.fleet_hosts(7, 6000, H, 100, 8)
+    dev_off = np.zeros(H + 1, dtype=np.uint32)
+    dev_off[1:] = np.cumsum(dev_cnt)
+    N = int(dev_off[H])
+    S, s_off = synth.modalias_strings(8, P, N)
+    rec = synth.device_records(9, S, s_off)
+    arena, off = synth.driver_names_packed()
+    ctx = gpu_ctx
+    d_rec, d_arena, d_off = ctx.to_device(rec), ctx.to_device(arena), ctx.to_device(off)
+    d_dev, d_S, d_soff = ctx.to_device(dev_off), ctx.to_device(S), ctx.to_device(s_off)
+    d_v, d_kept = ctx.alloc(N), ctx.alloc(4 * (H + 1))
+    D = len(off) - 1
+    # no limit: every verdict
+    K0 = ctx.device_filter_dev(d_rec.ptr, N, d_arena.ptr, d_off.ptr, D, d_dev.ptr, H, 0, d_v.ptr, d_kept.ptr)
+    v0 = d_v.download(np.uint8, N)
+    listed, excl = numpy_listed(rec, synth.DRIVER_NAMES)
+    assert np.array_equal((v0 & 1) != 0, listed) and np.array_equal((v0 & 2) != 0, excl)
+    assert K0 == int(listed.sum())
+    per_host = np.add.reduceat(listed.astype(np.int64), dev_off[:-1].astype(np.int64)) * (dev_cnt > 0)
+    assert np.array_equal(np.diff(d_kept.download(np.uint32, H + 1).astype(np.int64)), per_host)
+    # limit 64: the first 64 listed devices of every host, nothing else changes
+    K = ctx.device_filter_dev(d_rec.ptr, N, d_arena.ptr, d_off.ptr, D, d_dev.ptr, H, 64, d_v.ptr, d_kept.ptr)
+    v = d_v.download(np.uint8, N)
+    kept = d_kept.download(np.uint32, H + 1)
+    assert np.array_equal(np.diff(kept.astype(np.int64)), np.minimum(per_host, 64)) and K == kept[-1]
+    rank = np.cumsum(listed) - listed                       # listed devices before i, fleet-wide
+    host_of = np.repeat(np.arange(H), dev_cnt)
+    first_rank = np.concatenate([[0], np.cumsum(per_host)])[:-1]
+    in_host_rank = rank - first_rank[host_of]
+    assert np.array_equal((v & 1) != 0, listed & (in_host_rank < 64))
+    assert np.array_equal(v & 2, v0 & 2) and ((v >> 4) == 8).sum() == K0 - K
+    lo, hi = 5000, 5300
+    a, z = int(dev_off[lo]), int(dev_off[hi])
+    o_v, o_kept = oracle_mod.device_filter(rec[a:z], arena, off, dev_off[lo:hi + 1] - dev_off[lo], 64)
+    assert np.array_equal(v[a:z] & 3, o_v) and np.array_equal(kept[lo:hi + 1] - kept[lo], o_kept)
+    # packing: lengths, order and bytes of the kept strings
+    d_S2, d_soff2, d_src = ctx.alloc(len(S)), ctx.alloc(4 * (K + 1)), ctx.alloc(4 * K)
+    nbytes = ctx.fleet_compact_dev(d_v.ptr, d_S.ptr, d_soff.ptr, N, d_dev.ptr, H, d_kept.ptr, K, d_S2.ptr,
+                                   d_soff2.ptr, d_src.ptr)
+    keep = np.nonzero(v & 1)[0]
+    assert np.array_equal(d_src.download(np.uint32, K), keep.astype(np.uint32))
+    lens = np.diff(s_off.astype(np.int64))[keep]
+    off2 = d_soff2.download(np.uint32, K + 1)
+    assert np.array_equal(np.diff(off2.astype(np.int64)), lens) and nbytes == lens.sum()
+    S2 = d_S2.download(np.uint8, len(S))[:nbytes]
+    # gather the same bytes on the host: position p of the output comes from string keep[k] at p - off2[k]
+    k_of = np.repeat(np.arange(K), lens)
+    src_pos = s_off[keep][k_of].astype(np.int64) + (np.arange(nbytes) - off2[:-1][k_of].astype(np.int64))
+    assert np.array_equal(S2, S[src_pos])
+    for buf in (d_rec, d_arena, d_off, d_dev, d_S, d_soff, d_v, d_kept, d_S2, d_soff2, d_src):
+        buf.free()
