@@ -37,10 +37,9 @@ __device__ __forceinline__ uint32_t fl_owner(const uint32_t *__restrict__ off, u
 
 __device__ __forceinline__ void fl_set(uint32_t *M, uint32_t HW, uint32_t m, uint32_t h)
 {
-    uint32_t *w = &M[(size_t)m * HW + (h >> 5)];
-    const uint32_t bit = 1u << (h & 31u);
-    if (!(*w & bit))
-        atomicOr(w, bit);
+    /* no look before the OR: a host rarely names a module twice, so the read
+     * would only add a dependent round trip in front of nearly every atomic */
+    atomicOr(&M[(size_t)m * HW + (h >> 5)], 1u << (h & 31u));
 }
 
 /*
@@ -118,7 +117,19 @@ fl_level(const uint32_t *__restrict__ order, uint32_t n_rows, const uint32_t *__
     const uint32_t w = (uint32_t)(t % HW);
     uint32_t hold = 0;
     const uint32_t e1 = rrowptr[v + 1];
-    for (uint32_t e = rrowptr[v]; e < e1; ++e)
+    uint32_t e = rrowptr[v];
+    /* eight holders at a time: their ids, then their rows, each requested together
+     * (a core module has thousands of holders) */
+    for (; e + 8u <= e1; e += 8u) {
+        uint32_t u[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            u[k] = rcol[e + k];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            hold |= L[(size_t)u[k] * HW + w];
+    }
+    for (; e < e1; ++e)
         hold |= L[(size_t)rcol[e] * HW + w];
     const size_t at = (size_t)v * HW + w;
     const uint32_t used = U[at];
@@ -128,37 +139,47 @@ fl_level(const uint32_t *__restrict__ order, uint32_t n_rows, const uint32_t *__
 }
 
 /*
- * R -> per-host lists.  One thread per word column of R (32 hosts), walking the
- * modules in ascending order, so that every host's list comes out sorted and
- * R is read exactly once, coalesced (the set bits are sparse: the inner loop
- * rarely runs).  Each thread keeps its 32 list cursors in LDS.  FILL = false
- * counts (cnt[h] = entries of host h), FILL = true writes the module ids to
- * root_ids starting at root_off[h].
+ * R -> per-host lists.  One thread per word column of R (32 hosts) and row
+ * segment (FLC_SEGS segments of consecutive modules): a column alone would be
+ * H / 32 threads for the whole matrix.  A thread walks its rows in ascending
+ * order, FLC_ROWS of them under way at a time, reading R coalesced (the set
+ * bits are sparse: the inner loop rarely runs), with its 32 list cursors in
+ * LDS.  FILL = false counts: seg_cnt[seg][h] = entries of host h in segment
+ * seg.  fl_seg_prefix turns these into where each segment starts inside its
+ * host's list and the host totals; after the scan of the totals FILL = true
+ * writes the module ids from root_off[h] + seg_cnt[seg][h] on, so every host's
+ * list comes out sorted.
  */
 #define FLC_THREADS 64
+#define FLC_ROWS 32u
+#define FLC_SEGS 16u
 template <bool FILL>
 __global__ void __launch_bounds__(FLC_THREADS)
-fl_columns(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, uint32_t *__restrict__ cnt,
+fl_columns(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, uint32_t *__restrict__ seg_cnt,
            const uint32_t *__restrict__ root_off, uint32_t *__restrict__ root_ids)
 {
     __shared__ uint32_t cur[32][FLC_THREADS];
     const uint32_t tid = threadIdx.x;
     const uint32_t w = blockIdx.x * FLC_THREADS + tid;
+    const uint32_t seg = blockIdx.y;
     if (w >= HW)
         return;
+    const uint32_t rows = (V + FLC_SEGS - 1u) / FLC_SEGS;
+    const uint32_t v_lo = seg * rows, v_hi = min(V, v_lo + rows);
+    uint32_t *mine = seg_cnt + (size_t)seg * H;
 #pragma unroll
     for (uint32_t b = 0; b < 32u; ++b) {
         const uint32_t h = 32u * w + b;
-        cur[b][tid] = (FILL && h < H) ? root_off[h] : 0u;
+        cur[b][tid] = (FILL && h < H) ? root_off[h] + mine[h] : 0u;
     }
     const uint32_t *col = R + w;
-    for (uint32_t v0 = 0; v0 < V; v0 += 8u) {
-        uint32_t r[8];
+    for (uint32_t v0 = v_lo; v0 < v_hi; v0 += FLC_ROWS) {
+        uint32_t r[FLC_ROWS];
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k)
-            r[k] = v0 + k < V ? col[(size_t)(v0 + k) * HW] : 0u;
+        for (uint32_t k = 0; k < FLC_ROWS; ++k)
+            r[k] = v0 + k < v_hi ? col[(size_t)(v0 + k) * HW] : 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
+        for (uint32_t k = 0; k < FLC_ROWS; ++k) {
             uint32_t bits = r[k];
             while (bits) {
                 const uint32_t b = (uint32_t)__builtin_ctz(bits);
@@ -174,9 +195,28 @@ fl_columns(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, 
         for (uint32_t b = 0; b < 32u; ++b) {
             const uint32_t h = 32u * w + b;
             if (h < H)
-                cnt[h] = cur[b][tid];
+                mine[h] = cur[b][tid];
         }
     }
+}
+
+/* per host: seg_cnt[seg][h] -> entries of h in the segments before seg; cnt[h] = all of them */
+__global__ void __launch_bounds__(FL_THREADS)
+fl_seg_prefix(uint32_t *__restrict__ seg_cnt, uint32_t H, uint32_t *__restrict__ cnt)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H)
+        return;
+    uint32_t c[FLC_SEGS], run = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < FLC_SEGS; ++s)
+        c[s] = seg_cnt[(size_t)s * H + h];
+#pragma unroll
+    for (uint32_t s = 0; s < FLC_SEGS; ++s) {
+        seg_cnt[(size_t)s * H + h] = run;
+        run += c[s];
+    }
+    cnt[h] = run;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -215,7 +255,8 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
     const size_t mat = up256(4 * (size_t)(V ? V : 1) * HW);
     const size_t o_first = 2 * mat, o_count = o_first + up256(4 * (size_t)(N ? N : 1));
     const size_t o_cnt = o_count + up256(4 * (size_t)(N ? N : 1)), o_bsum = o_cnt + up256(4 * (size_t)H);
-    const size_t o_hw = o_bsum + up256(4 * (size_t)nb), o_total = o_hw + up256(V ? V : 1);
+    const size_t o_hw = o_bsum + up256(4 * (size_t)nb), o_seg = o_hw + up256(V ? V : 1);
+    const size_t o_total = o_seg + up256(4 * (size_t)FLC_SEGS * H);
     void *base;
     int rc = mcx_scratch(ctx, o_total + 256, &base);
     if (rc != MCX_OK)
@@ -223,6 +264,8 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
     uint32_t *U = (uint32_t *)base, *L = (uint32_t *)((char *)base + mat);
     uint32_t *d_first = (uint32_t *)((char *)base + o_first), *d_count = (uint32_t *)((char *)base + o_count);
     uint32_t *d_cnt = (uint32_t *)((char *)base + o_cnt), *d_bsum = (uint32_t *)((char *)base + o_bsum);
+    uint32_t *d_seg = (uint32_t *)((char *)base + o_seg);
+    const dim3 col_grid((HW + FLC_THREADS - 1) / FLC_THREADS, FLC_SEGS);
     uint8_t *d_hw = (uint8_t *)base + o_hw;
     unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
 
@@ -250,8 +293,8 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
                                                                   ctx->d_rcol, (const uint8_t *)d_safe_name, d_hw,
                                                                   HW, U, L);
     }
-    fl_columns<false><<<(HW + FLC_THREADS - 1) / FLC_THREADS, FLC_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_cnt,
-                                                                                             nullptr, nullptr);
+    fl_columns<false><<<col_grid, FLC_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_seg, nullptr, nullptr);
+    fl_seg_prefix<<<(H + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(d_seg, H, d_cnt);
     fl_scan_sums<<<nb, FL_THREADS, 0, ctx->stream>>>(d_cnt, H, d_bsum);
     fl_scan_top<<<1, FL_THREADS, 0, ctx->stream>>>(d_bsum, nb, d_total);
     fl_scan_apply<<<nb, FL_THREADS, 0, ctx->stream>>>(d_cnt, H, d_bsum, (uint32_t *)d_root_off);
@@ -269,8 +312,9 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
         return MCX_E_TOO_LARGE;
     }
     if (*h_total)
-        fl_columns<true><<<(HW + FLC_THREADS - 1) / FLC_THREADS, FLC_THREADS, 0, ctx->stream>>>(
-            U, V, H, HW, nullptr, (const uint32_t *)d_root_off, (uint32_t *)d_root_ids);
+        fl_columns<true><<<col_grid, FLC_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_seg,
+                                                                    (const uint32_t *)d_root_off,
+                                                                    (uint32_t *)d_root_ids);
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
 }
