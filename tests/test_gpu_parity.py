@@ -429,3 +429,20 @@ def test_text_tables_dashboard_flow(gpu_ctx, oracle_mod):
         assert roots == ["e1000e", "igb"]          # snd_* fails the name filter, the others are held
         held = sorted(names[i] for i in np.nonzero(out & 1)[0])
         assert held == ["pps_core", "ptp", "snd_hda_core"]
+
+
+def test_k2_golden(gpu_ctx):
+    """the committed K2 vectors (hand-made chain and diamond, frozen random graph) through the C ABI"""
+    for c in load("k2_golden.json")["cases"]:
+        V = c["V"]
+        seeds = np.zeros((V + 31) // 32, dtype=np.uint32)
+        for v in c["seeds"]:
+            seeds[v >> 5] |= np.uint32(1 << (v & 31))
+        flags = np.array(c["in_flags"], np.uint8)
+        gpu_ctx.dep_graph_load(np.array(c["rowptr"], np.uint32), np.array(c["col"], np.uint32))
+        out, ref = gpu_ctx.dep_flags(flags)
+        assert out.tolist() == c["out_flags"] and ref.tolist() == c["refcnt"], c["name"]
+        for direction, key in ((0, "closure_holders"), (1, "closure_deps")):
+            clo, edges, levels = gpu_ctx.dep_closure(flags, seeds, direction)
+            members = [v for v in range(V) if clo[v >> 5] >> (v & 31) & 1]
+            assert members == c[key]["members"] and edges == c[key]["edges"] and levels == c[key]["levels"]

@@ -333,3 +333,23 @@ def test_hw_alias_stage(oracle_mod):
     assert lib.orc_has_hw_alias(b"fs-ext4\n\tof:N*T*Cx\n") == 1
     assert lib.orc_has_hw_alias(b"") == 0
     assert lib.orc_has_hw_alias(b"xpci:v*") == 0
+
+
+def _k2_golden_case(c):
+    V = c["V"]
+    seeds = np.zeros((V + 31) // 32, dtype=np.uint32)
+    for v in c["seeds"]:
+        seeds[v >> 5] |= np.uint32(1 << (v & 31))
+    return (np.array(c["rowptr"], np.uint32), np.array(c["col"], np.uint32), np.array(c["in_flags"], np.uint8), seeds)
+
+
+def test_oracle_k2_golden(oracle_mod):
+    """chain and diamond worked out by hand, a frozen random graph (tests/golden/make_k2_golden.py)"""
+    for c in load("k2_golden.json")["cases"]:
+        rowptr, col, flags, seeds = _k2_golden_case(c)
+        out, ref = oracle_mod.dep_flags(rowptr, col, flags)
+        assert out.tolist() == c["out_flags"] and ref.tolist() == c["refcnt"], c["name"]
+        for direction, key in ((0, "closure_holders"), (1, "closure_deps")):
+            clo, edges, levels = oracle_mod.dep_closure(rowptr, col, flags, seeds, direction)
+            members = [v for v in range(c["V"]) if clo[v >> 5] >> (v & 31) & 1]
+            assert members == c[key]["members"] and edges == c[key]["edges"] and levels == c[key]["levels"]
