@@ -38,7 +38,7 @@ struct k1_table_t {
     const uint32_t *lens;   /* nlens key lengths                               */
     uint32_t slot_mask;
     uint32_t nlens;
-    uint32_t nlens_magic;   /* ceil(2^32 / nlens): x / nlens = mulhi(x, magic) for x < 2^16 */
+    uint32_t nlens_magic;   /* ceil(2^32 / nlens): x / nlens = mulhi(x, magic) for x < 2^16, nlens >= 2 */
     uint32_t norm_dash;     /* strings get kmod's '-' -> '_' rule before they are matched */
 };
 
@@ -363,7 +363,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 #endif
     const uint32_t nprobe = nstr * T.nlens;
     for (uint32_t pr = (K1_THREADS - 1u) - tid; pr < nprobe; pr += K1_THREADS) {
-        const uint32_t slot = __umulhi(pr, T.nlens_magic), L = key_lens[pr - slot * T.nlens];
+        /* pr / nlens; a table with a single key length has no 32-bit reciprocal */
+        const uint32_t slot = T.nlens == 1u ? pr : __umulhi(pr, T.nlens_magic), L = key_lens[pr - slot * T.nlens];
         const uint32_t len = str_len[slot];
         if (L > len)
             continue;

@@ -1,0 +1,85 @@
+"""Soak run: many seeded tables and batches of every shape through the GPU matcher, each
+checked against the CPU twin (itself pinned to glibc fnmatch by the CPU suite); a sample of
+every case also against glibc directly.  Prints a line per case; stops at the first mismatch.
+env: SOAK_SECONDS (default 150), SOAK_SEED."""
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import oracle  # noqa: E402
+from montecarlo_amd import Context, synth  # noqa: E402
+from montecarlo_amd.binding import pack_strings  # noqa: E402
+
+budget = float(os.environ.get("SOAK_SECONDS", 150))
+rnd = random.Random(int(os.environ.get("SOAK_SEED", 1)))
+tw = oracle.twin()
+dump_case = int(os.environ.get("SOAK_DUMP_CASE", 0))   # write the inputs of that case to /tmp and stop (no GPU)
+ctx = None if dump_case else Context(0)
+t_end = time.time() + budget
+case = 0
+
+
+def metachar_table(n_pat, n_str, alphabet_p, alphabet_s, max_p, max_s):
+    pats = []
+    while len(pats) < n_pat:
+        p = bytes(rnd.choice(alphabet_p) for _ in range(rnd.randint(0, max_p)))
+        if tw.twin_compile_check(p, len(p), 0) == 0:
+            pats.append(p)
+    strs = [bytes(rnd.choice(alphabet_s) for _ in range(rnd.randint(0, max_s))) for _ in range(n_str)]
+    return pack_strings(pats), pack_strings(strs)
+
+
+while time.time() < t_end:
+    case += 1
+    kind = rnd.choice(["synth", "synth", "synth", "meta", "meta_long", "dup"])
+    norm = rnd.random() < 0.3
+    if kind in ("synth", "dup"):
+        seed = rnd.randint(1, 10**6)
+        P = rnd.choice([1, 7, 100, 1000, 5000, 30000, 60000])
+        N = rnd.choice([1, 3, 64, 65, 500, 2049, 9000, 66000, 150000])
+        A, a_off, _ = synth.alias_table(seed, P)
+        S, s_off = synth.modalias_strings(seed + rnd.randint(0, 1), P, N)
+        if kind == "dup":                      # repeated texts, table order shuffled in blocks
+            raw = A.tobytes()
+            pats = [raw[a_off[j]:a_off[j + 1]] for j in range(P)]
+            pats = pats[::3] + pats
+            A, a_off = pack_strings(pats)
+        norm = False if kind == "dup" else norm
+    elif kind == "meta":
+        (A, a_off), (S, s_off) = metachar_table(rnd.randint(1, 800), rnd.randint(1, 400), b"ab[]!^-\\*?c",
+                                                b"ab[]-\\c!^*?", 9, 7)
+        norm = False
+    else:
+        (A, a_off), (S, s_off) = metachar_table(rnd.randint(1, 300), rnd.randint(1, 300), b"abc*?[]-x:0123",
+                                                b"abcx:0123-", 90, 100)
+    P, N = len(a_off) - 1, len(s_off) - 1
+    if dump_case:
+        if case == dump_case:
+            np.savez("/tmp/soak_case.npz", A=A, a_off=a_off, S=S, s_off=s_off, norm=norm)
+            print("dumped case", case, kind, P, N)
+            sys.exit(0)
+        rnd.sample(range(N), min(N, 3 if P > 20000 else 12))
+        continue
+    try:
+        ctx.alias_table_load(A, a_off, np.zeros(P, dtype=np.uint32), flags=1 if norm else 0)
+    except Exception as e:                     # noqa: BLE001 - a table kmod's rule refuses: skip
+        print(f"case {case}: {kind} P={P} refused at load ({e})", flush=True)
+        continue
+    first, count = ctx.alias_match(S, s_off)
+    t_first, t_count = oracle.alias_match(A, a_off, S, s_off, normalize_dash=norm, use_twin=True)
+    ok = np.array_equal(first, t_first) and np.array_equal(count, t_count)
+    pick = sorted(rnd.sample(range(N), min(N, 3 if P > 20000 else 12)))
+    Ss, ss_off = pack_strings([S[s_off[i]:s_off[i + 1]].tobytes() for i in pick])
+    g_first, g_count = oracle.alias_match(A, a_off, Ss, ss_off, normalize_dash=norm)
+    ok = ok and np.array_equal(first[pick], g_first) and np.array_equal(count[pick], g_count)
+    print(f"case {case}: {kind} P={P} N={N} norm={int(norm)} matches={int(count.sum())} {'ok' if ok else 'MISMATCH'}",
+          flush=True)
+    if not ok:
+        bad = np.nonzero((first != t_first) | (count != t_count))[0][:5]
+        print("first mismatching strings:", bad.tolist(), first[bad].tolist(), t_first[bad].tolist(), flush=True)
+        sys.exit(1)
+print(f"soak ok: {case} cases", flush=True)

@@ -141,6 +141,26 @@ def test_k1_edge_cases(gpu_ctx, oracle_mod):
     assert (f == NO_MATCH).all() and (c == 0).all()
 
 
+@pytest.mark.parametrize("N", [1, 2049, 5000, 70000])
+def test_k1_single_key_length_tables(gpu_ctx, oracle_mod, N):
+    """tables whose patterns all share one literal-prefix length (one probe per string), with
+    batches cut at one, two, three and eight strings per block"""
+    pats = [b"serio:ty07pr*id*ex97", b"serio:ty07pr*id*ex97", b"serio:ty07pr0?id*", b"serio:ty06pr*"]
+    rng = np.random.default_rng(N)
+    strs = [b"serio:ty0%dpr%02Xid%02Xex%02X" % (rng.integers(6, 8), rng.integers(0, 256), rng.integers(0, 256),
+                                              rng.choice([0x97, 0x12])) for _ in range(N)]
+    A, a_off = pack_strings(pats)
+    S, s_off = pack_strings(strs)
+    gpu_ctx.alias_table_load(A, a_off, np.zeros(len(pats), dtype=np.uint32))
+    first, count = gpu_ctx.alias_match(S, s_off)
+    t_first, t_count = oracle_mod.alias_match(A, a_off, S, s_off, use_twin=True)
+    assert np.array_equal(first, t_first) and np.array_equal(count, t_count)
+    n = min(N, 300)
+    o_first, o_count = oracle_mod.alias_match(A, a_off, S, s_off, i0=0, i1=n)
+    assert np.array_equal(first[:n], o_first) and np.array_equal(count[:n], o_count)
+    assert (count > 0).any() or N == 1
+
+
 def test_k1_random_metachar_tables(gpu_ctx, oracle_mod):
     """random patterns heavy in metacharacters (those the compiler accepts)"""
     import random
