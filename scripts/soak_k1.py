@@ -35,7 +35,7 @@ def metachar_table(n_pat, n_str, alphabet_p, alphabet_s, max_p, max_s):
 
 while time.time() < t_end:
     case += 1
-    kind = rnd.choice(["synth", "synth", "synth", "meta", "meta_long", "dup"])
+    kind = rnd.choice(["synth", "synth", "synth", "meta", "meta_long", "dup", "longstr", "bigtable"])
     norm = rnd.random() < 0.3
     if kind in ("synth", "dup"):
         seed = rnd.randint(1, 10**6)
@@ -49,6 +49,27 @@ while time.time() < t_end:
             pats = pats[::3] + pats
             A, a_off = pack_strings(pats)
         norm = False if kind == "dup" else norm
+    elif kind == "longstr":
+        # strings on both sides of the 64-byte and of the tile-buffer limits: tails appended to seeded strings
+        seed = rnd.randint(1, 10**6)
+        P, N = rnd.choice([100, 3000, 30000]), rnd.choice([5, 300, 2100, 70000])
+        A, a_off, _ = synth.alias_table(seed, P)
+        S0, s0 = synth.modalias_strings(seed, P, N)
+        raw = S0.tobytes()
+        strs = []
+        for i in range(N):
+            t = raw[s0[i]:s0[i + 1]]
+            r = rnd.random()
+            if r < 0.3:
+                t += bytes(rnd.choice(b"0123456789ABCDEFscbi-") for _ in range(rnd.choice([1, 9, 20, 70, 300, 2500])))
+            strs.append(t)
+        S, s_off = pack_strings(strs)
+    elif kind == "bigtable":
+        seed = rnd.randint(1, 10**6)
+        P, N = rnd.choice([300000, 1000000]), rnd.choice([40, 3000, 66000])
+        A, a_off, _ = synth.alias_table(seed, P)
+        S, s_off = synth.modalias_strings(seed, P, N)
+        norm = False
     elif kind == "meta":
         (A, a_off), (S, s_off) = metachar_table(rnd.randint(1, 800), rnd.randint(1, 400), b"ab[]!^-\\*?c",
                                                 b"ab[]-\\c!^*?", 9, 7)
