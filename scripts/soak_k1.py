@@ -23,11 +23,11 @@ t_end = time.time() + budget
 case = 0
 
 
-def metachar_table(n_pat, n_str, alphabet_p, alphabet_s, max_p, max_s):
+def metachar_table(n_pat, n_str, alphabet_p, alphabet_s, max_p, max_s, normalize=0):
     pats = []
     while len(pats) < n_pat:
         p = bytes(rnd.choice(alphabet_p) for _ in range(rnd.randint(0, max_p)))
-        if tw.twin_compile_check(p, len(p), 0) == 0:
+        if tw.twin_compile_check(p, len(p), normalize) == 0:
             pats.append(p)
     strs = [bytes(rnd.choice(alphabet_s) for _ in range(rnd.randint(0, max_s))) for _ in range(n_str)]
     return pack_strings(pats), pack_strings(strs)
@@ -35,7 +35,7 @@ def metachar_table(n_pat, n_str, alphabet_p, alphabet_s, max_p, max_s):
 
 while time.time() < t_end:
     case += 1
-    kind = rnd.choice(["synth", "synth", "synth", "meta", "meta_long", "dup", "longstr", "bigtable"])
+    kind = rnd.choice(["synth", "synth", "synth", "meta", "meta_long", "dup", "longstr", "bigtable", "meta_norm"])
     norm = rnd.random() < 0.3
     if kind in ("synth", "dup"):
         seed = rnd.randint(1, 10**6)
@@ -70,6 +70,11 @@ while time.time() < t_end:
         A, a_off, _ = synth.alias_table(seed, P)
         S, s_off = synth.modalias_strings(seed, P, N)
         norm = False
+    elif kind == "meta_norm":
+        # kmod's dash rule on patterns and on queried strings, brackets and dashes everywhere
+        (A, a_off), (S, s_off) = metachar_table(rnd.randint(1, 500), rnd.choice([1, 300, 2100, 66000]),
+                                                b"ab-_[]*?c-", b"ab-_[]c-_", 12, 10, normalize=1)
+        norm = True
     elif kind == "meta":
         (A, a_off), (S, s_off) = metachar_table(rnd.randint(1, 800), rnd.randint(1, 400), b"ab[]!^-\\*?c",
                                                 b"ab[]-\\c!^*?", 9, 7)
