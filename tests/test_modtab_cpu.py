@@ -135,3 +135,40 @@ def test_load_dir(tmp_path):
         assert t.counts()[:2] == (7, 14)
     with ModTab() as t, pytest.raises(McxError):
         t.load_dir(str(tmp_path / "missing"))
+
+
+def test_dep_text_fuzz_direct_edges():
+    """random dependency DAGs without redundant edges, written the way depmod writes them (every
+    line lists all that the module needs, directly or not): the table's direct edges are the DAG's,
+    its flat lists are the file's"""
+    rng = np.random.default_rng(3)
+    for trial in range(30):
+        V = int(rng.integers(2, 60))
+        need = [set() for _ in range(V)]          # direct, u needs v only for v < u
+        reach = [set() for _ in range(V)]
+        for u in range(1, V):
+            for v in rng.permutation(u)[: int(rng.integers(0, 4))]:
+                v = int(v)
+                if v in reach[u]:
+                    continue                      # would be a redundant edge
+                # adding u -> v must not make an earlier direct edge of u redundant
+                if any(w in reach[v] for w in need[u]):
+                    continue
+                need[u].add(v)
+                reach[u] |= {v} | reach[v]
+        names = [f"mod-{k}" if k % 3 else f"m{k}" for k in range(V)]
+        lines = []
+        for u in rng.permutation(V):
+            deps = sorted(reach[u], reverse=True)
+            lines.append(f"kernel/x/{names[u]}.ko.zst:" + "".join(f" kernel/y/{names[d]}.ko.zst" for d in deps))
+        with ModTab() as t:
+            t.add_dep_text("\n".join(lines) + "\n")
+            ids = {n: t.module_id(n) for n in names}
+            assert sorted(ids.values()) == list(range(V))
+            back = {i: k for k, i in ((k, ids[names[k]]) for k in range(V))}
+            rowptr, col = t.dep_arrays(direct=True)
+            frow, fcol = t.dep_arrays(direct=False)
+            for k in range(V):
+                i = ids[names[k]]
+                assert {back[int(x)] for x in col[rowptr[i]:rowptr[i + 1]]} == need[k], (trial, k)
+                assert {back[int(x)] for x in fcol[frow[i]:frow[i + 1]]} == reach[k], (trial, k)
