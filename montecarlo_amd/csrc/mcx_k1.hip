@@ -22,6 +22,9 @@
 #define K1_LDS_STR_BYTES 8192               /* staging buffer for a tile       */
 #define K1_RING 2048u       /* survivors waiting for a program run, per block    */
 #define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
+#define K1_MAX_PATTERNS (1u << 26) /* survivor entries and group counts keep a pattern number in 26 bits */
+#define K1_QUARTER 64u      /* a group of at most this many patterns takes a quarter of a
+                               step (16 lanes): four such groups share one          */
 #define K1_GROUP 16u        /* survivors one wave stages per pass                 */
 #define K1_SUB 8u           /* of which it runs eight at a time, eight lanes each */
 #define K1_STAGE_STRIDE (MCX_SLOT_WORDS + 1u) /* odd: lanes reading the same word
@@ -256,7 +259,8 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     K1_STAMP(0);
     /* dynamic LDS, sized by the launch for its strings-per-block:
      * [spb occurrence tables][str_cap/4 + 5 words of string bytes]
-     * [hit_start][hit_slot][hit_cnt][hit_ub], max_hits words each */
+     * [hit_start][hit_cnt][hit_ub][qhit], max_hits words each (hit_cnt: pattern
+     * count in bits 0..25, string slot above) */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
     __shared__ uint32_t ring[K1_RING];
     __shared__ uint32_t stage[BULK ? 1 : K1_WAVES][BULK ? 1 : K1_STAGE_WORDS];
@@ -268,14 +272,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
     __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB], refused[K1_MAX_SPB];
     __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
-    __shared__ uint32_t nhits, nunits_sh, ring_cum[2];
+    __shared__ uint32_t nhits, nunits_sh, nq_sh, ring_cum[2];
     const uint32_t max_hits = spb * T.nlens;
     uint32_t *occ_w = k1_lds;
     uint32_t *str_w = occ_w + spb * K1_OCC_WORDS;
     uint32_t *hit_start = str_w + str_cap / 4u + 5u;
-    uint32_t *hit_slot = hit_start + max_hits;
-    uint32_t *hit_cnt = hit_slot + max_hits;
+    uint32_t *hit_cnt = hit_start + max_hits;
     uint32_t *hit_ub = hit_cnt + max_hits;
+    uint32_t *qhit = hit_ub + max_hits; /* small groups in order of arrival: their hit numbers */
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -313,6 +317,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     if (tid == 0) {
         nhits = 0;
         nunits_sh = 0;
+        nq_sh = 0;
         ring_cum[0] = 0;
         ring_cum[1] = 0;
     }
@@ -402,10 +407,15 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                  * unit space, in whatever order the hits arrive */
                 const uint32_t units = (sl.count + K1_UNIT - 1u) / K1_UNIT;
                 const uint32_t h = atomicAdd(&nhits, 1u);
-                hit_ub[h] = atomicAdd(&nunits_sh, units);
+                if (sl.count > K1_QUARTER) {
+                    hit_ub[h] = atomicAdd(&nunits_sh, units);
+                } else {
+                    /* a small group: a quarter of one of the units behind the large groups' */
+                    qhit[atomicAdd(&nq_sh, 1u)] = h;
+                    hit_ub[h] = 0xFFFFFFFFu;
+                }
                 hit_start[h] = sl.start;
-                hit_slot[h] = slot;
-                hit_cnt[h] = sl.count;
+                hit_cnt[h] = sl.count | (slot << 26);
                 break;
             }
         }
@@ -422,20 +432,36 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 
     /* ---- units -> survivors ----------------------------------------------- */
     const uint32_t nh = nhits;
-    const uint32_t nunits = nunits_sh;
+    const uint32_t nbig = nunits_sh, nq = nq_sh;
+    const uint32_t nunits = nbig + (nq + 3u) / 4u;
     /* the first 64 hits live in registers, one per lane */
     uint32_t my_ub = 0, my_units = 0, my_start = 0, my_cnt = 0, my_slot = 0;
     if (lane < nh) {
         my_ub = hit_ub[lane];
-        my_cnt = hit_cnt[lane];
-        my_units = (my_cnt + K1_UNIT - 1u) / K1_UNIT;
+        my_cnt = hit_cnt[lane] & 0x03FFFFFFu;
+        my_slot = hit_cnt[lane] >> 26;
+        my_units = my_ub == 0xFFFFFFFFu ? 0u : (my_cnt + K1_UNIT - 1u) / K1_UNIT;
         my_start = hit_start[lane];
-        my_slot = hit_slot[lane];
     }
-    /* unit u -> first pattern, number of patterns, string slot */
-    auto unit_at = [&](uint32_t u, uint32_t &k0, uint32_t &n, uint32_t &slot) __attribute__((always_inline)) {
-        const unsigned long long m = __ballot(u - my_ub < my_units); /* lanes without a hit: 0 units */
-        uint32_t ub, cnt, start;
+    /* unit u -> per lane: first of its four patterns, how many of the four exist, string slot.
+     * Units below nbig are 256 consecutive patterns of one large group; the ones
+     * behind them hold four small groups, one per 16 lanes. */
+    auto unit_at = [&](uint32_t u, uint32_t &pk, uint32_t &pn, uint32_t &pslot) __attribute__((always_inline)) {
+        if (u >= nbig) {
+            const uint32_t q = 4u * (u - nbig) + (lane >> 4), sub = 4u * (lane & 15u);
+            pk = 0;
+            pn = 0;
+            pslot = 0;
+            if (q < nq) {
+                const uint32_t h = qhit[q], cs = hit_cnt[h], cnt = cs & 0x03FFFFFFu;
+                pk = hit_start[h] + sub;
+                pn = cnt > sub ? min(4u, cnt - sub) : 0u;
+                pslot = cs >> 26;
+            }
+            return;
+        }
+        const unsigned long long m = __ballot(u - my_ub < my_units); /* lanes without a large group: 0 units */
+        uint32_t ub, cnt, start, slot;
         if (m) {
             const uint32_t src = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(m));
             ub = __builtin_amdgcn_readlane(my_ub, src);
@@ -443,27 +469,30 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             start = __builtin_amdgcn_readlane(my_start, src);
             slot = __builtin_amdgcn_readlane(my_slot, src);
         } else {
-            /* more than 64 hits in the block: the rest is searched in LDS */
+            /* more than 64 hits in the block: the rest is searched in LDS (a
+             * small group's base is 2^32 - 1: it never holds u) */
             uint32_t h = 64u;
-            while (u - hit_ub[h] >= (hit_cnt[h] + K1_UNIT - 1u) / K1_UNIT)
+            while (u - hit_ub[h] >= ((hit_cnt[h] & 0x03FFFFFFu) + K1_UNIT - 1u) / K1_UNIT)
                 ++h;
             ub = hit_ub[h];
-            cnt = hit_cnt[h];
+            cnt = hit_cnt[h] & 0x03FFFFFFu;
             start = hit_start[h];
-            slot = hit_slot[h];
+            slot = hit_cnt[h] >> 26;
         }
         const uint32_t j = u - ub;
-        k0 = start + K1_UNIT * j;
-        n = min(K1_UNIT, cnt - K1_UNIT * j);
+        const uint32_t n = min(K1_UNIT, cnt - K1_UNIT * j);
+        pk = start + K1_UNIT * j + 4u * lane;
+        pn = n > 4u * lane ? min(4u, n - 4u * lane) : 0u;
+        pslot = slot;
     };
-    auto load_sigs = [&](uint32_t k0, uint32_t n, k1_sig4_t &out) __attribute__((always_inline)) {
+    auto load_sigs = [&](uint32_t pk, uint32_t pn, k1_sig4_t &out) __attribute__((always_inline)) {
 #pragma unroll
         for (uint32_t jj = 0; jj < 4; ++jj)
             out.v[jj] = 0u;
         /* a partly used group of four reads up to three signatures past the
-         * unit: the array is padded for that */
-        if (4u * lane < n)
-            out = *(const k1_sig4_t *)(T.sig + k0 + 4u * lane);
+         * group: the array is padded for that */
+        if (pn)
+            out = *(const k1_sig4_t *)(T.sig + pk);
     };
 
     /* run n <= K1_GROUP survivors ring[from .. from+n): all their slots are
@@ -623,7 +652,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
      * every wave has passed the barrier of round r+1), so every thread reads
      * the same value and keeps the ring's head and tail in registers. */
     uint32_t head = 0, tail = 0, seen0 = 0, seen1 = 0;
-    uint32_t k0 = 0, n = 0, slot = 0;
+    uint32_t k0 = 0, n = 0, slot = 0; /* this lane's four patterns: first, how many exist, string slot */
     k1_sig4_t cur;
     if (wave < nunits) {
         unit_at(wave, k0, n, slot);
@@ -640,14 +669,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             load_sigs(nk0, nn, nxt);
         }
         if (u < nunits) {
-            const uint8_t *bl = bloom[slot];
+            const uint8_t *bl = bloom[slot]; /* per lane: a unit of small groups spans strings */
             bool pass[4];
 #pragma unroll
             for (uint32_t jj = 0; jj < 4; ++jj) {
                 /* the four bits the signature names, read together */
                 const uint32_t sg = cur.v[jj];
                 const uint32_t all = bl[sg & 0xFFu] & bl[(sg >> 8) & 0xFFu] & bl[(sg >> 16) & 0xFFu] & bl[sg >> 24];
-                pass[jj] = (4u * lane + jj < n) && all != 0u;
+                pass[jj] = jj < n && all != 0u;
             }
             /* one reservation per wave; the order of the survivors in the ring
              * does not matter, so every one of the four pattern columns is
@@ -670,7 +699,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                     if (pass[jj]) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
                             (uint32_t)(bm[jj] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[jj], 0u));
-                        ring[(base + col[jj] + rank) & (K1_RING - 1u)] = (slot << 26) | (k0 + 4u * lane + jj);
+                        ring[(base + col[jj] + rank) & (K1_RING - 1u)] = (slot << 26) | (k0 + jj);
                     }
             }
         }
@@ -818,6 +847,10 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
         ctx->err = "unknown table flag";
         return MCX_E_BAD_ARG;
     }
+    if (P > K1_MAX_PATTERNS) {
+        ctx->err = "alias table too large: at most 2^26 patterns (shard it)";
+        return MCX_E_BAD_ARG;
+    }
     if (mcx_set_device(ctx))
         return MCX_E_HIP;
     mcx_compiled_table t;
@@ -914,6 +947,9 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         str_cap = 1024u;
     if (str_cap > K1_LDS_STR_BYTES)
         str_cap = K1_LDS_STR_BYTES;
+    /* five blocks of a large batch fit one CU's LDS with a few hundred bytes to spare: nothing
+     * may be added to this without looking at the occupancy */
+    const bool bulk = N >= 65536u;
     size_t lds = 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)str_cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
     const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
 #ifdef MCX_K1_STAMPS
@@ -927,7 +963,6 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     /* eight lanes per survivor while a block's waves see few survivors at a
      * time; a lane per survivor once every pass fills its wave (measured: the
      * two meet at about 10^5 strings against 3 x 10^4 patterns) */
-    const bool bulk = N >= 65536u;
     const k1_list_t L{d_list_off, d_list_idx, ctx->d_dup_start, ctx->d_dup_idx};
     if (d_list_off && bulk)
         k1_match_indexed<true, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
