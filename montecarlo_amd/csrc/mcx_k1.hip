@@ -23,6 +23,8 @@
 #define K1_RING 2048u       /* survivors waiting for a program run, per block    */
 #define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
 #define K1_MAX_PATTERNS (1u << 26) /* survivor entries and group counts keep a pattern number in 26 bits */
+#define K1_CU_LDS_BYTES 163840u /* LDS of one gfx950 CU */
+#define K1_LDS_GRANULE 1280u    /* ... allocated to blocks in pieces of this size */
 #define K1_QUARTER 64u      /* a group of at most this many patterns takes a quarter of a
                                step (16 lanes): four such groups share one          */
 #define K1_GROUP 16u        /* survivors one wave stages per pass                 */
@@ -262,7 +264,11 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
      * [hit_start][hit_cnt][hit_ub][qhit], max_hits words each (hit_cnt: pattern
      * count in bits 0..25, string slot above) */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
-    __shared__ uint32_t ring[K1_RING];
+    /* survivors waiting for a program run.  A round adds at most K1_WAVES x K1_UNIT and leaves
+     * less than K1_WAVES x GROUP behind; large batches take the smaller ring so that five
+     * blocks fit a CU's LDS whatever the table's number of key lengths */
+    constexpr uint32_t RING = BULK ? 1536u : K1_RING;
+    __shared__ uint32_t ring[RING];
     __shared__ uint32_t stage[BULK ? 1 : K1_WAVES][BULK ? 1 : K1_STAGE_WORDS];
     constexpr uint32_t GROUP = BULK ? 64u : K1_GROUP; /* survivors one wave takes per pass */
     /* gram set of each string, one byte per bit number: the screen reads it with
@@ -530,7 +536,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
      * waves of the other blocks on the CU cover the memory latency */
     auto run_lanes = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
         if (lane < n) {
-            const uint32_t e = ring[(from + lane) & (K1_RING - 1u)];
+            const uint32_t e = ring[(from + lane) % RING];
             const uint32_t slot = e >> 26;
             const uint32_t len = str_len[slot];
             const uint32_t *sp = T.slot + (size_t)(e & 0x03FFFFFFu) * MCX_SLOT_WORDS;
@@ -554,7 +560,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             const uint32_t piece = lane + 64u * t, i = piece / (MCX_SLOT_WORDS / 4u),
                            quarter = piece % (MCX_SLOT_WORDS / 4u);
             if (i < n) {
-                const uint32_t kk = ring[(from + i) & (K1_RING - 1u)] & 0x03FFFFFFu;
+                const uint32_t kk = ring[(from + i) % RING] & 0x03FFFFFFu;
                 const uint4 v = *(const uint4 *)(T.slot + (size_t)kk * MCX_SLOT_WORDS + 4u * quarter);
                 uint32_t *dst = my_stage + i * K1_STAGE_STRIDE + 4u * quarter;
                 dst[0] = v.x;
@@ -572,7 +578,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         for (uint32_t g = lane >> 3; g < n; g += K1_SUB) {
             K1_TICK();
             /* the eight lanes of a group stay together: g < n is the same for them */
-            const uint32_t slot = ring[(from + g) & (K1_RING - 1u)] >> 26;
+            const uint32_t slot = ring[(from + g) % RING] >> 26;
             const uint32_t *st = my_stage + g * K1_STAGE_STRIDE;
             const LdsProg lp{(lds_words_t)st};
             const uint32_t hdr = lp[0];
@@ -625,7 +631,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 ok = pre && k == 7u && MCX_STATE_OK(state) != 0u;
             }
             if (ok)
-                hit(slot, ring[(from + g) & (K1_RING - 1u)] & 0x03FFFFFFu, lp[1], lp[MCX_SLOT_MULT]);
+                hit(slot, ring[(from + g) % RING] & 0x03FFFFFFu, lp[1], lp[MCX_SLOT_MULT]);
             K1_TOCK(acc_comb);
 #ifdef MCX_K1_STAMPS
             ++acc_n;
@@ -699,7 +705,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                     if (pass[jj]) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
                             (uint32_t)(bm[jj] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[jj], 0u));
-                        ring[(base + col[jj] + rank) & (K1_RING - 1u)] = (slot << 26) | (k0 + jj);
+                        ring[(base + col[jj] + rank) % RING] = (slot << 26) | (k0 + jj);
                     }
             }
         }
@@ -727,7 +733,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             head += GROUP * groups;
             /* next round's survivors may only overwrite entries that have been
              * run: make sure of it when this round ran a large part of the ring */
-            if (GROUP * groups > K1_RING / 4u)
+            if (GROUP * groups + K1_WAVES * GROUP + K1_WAVES * K1_UNIT > RING)
                 __syncthreads();
         }
     }
@@ -948,9 +954,26 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     if (str_cap > K1_LDS_STR_BYTES)
         str_cap = K1_LDS_STR_BYTES;
     /* five blocks of a large batch fit one CU's LDS with a few hundred bytes to spare: nothing
-     * may be added to this without looking at the occupancy */
+     * may be added to this without looking at the occupancy.  A table with many key lengths
+     * has larger hit arrays; the staging buffer then gives way (down to 128 bytes per string)
+     * so that the fifth block still fits. */
     const bool bulk = N >= 65536u;
-    size_t lds = 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)str_cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
+    auto lds_bytes = [&](uint32_t cap) {
+        return 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
+    };
+    if (bulk) {
+        static size_t static_lds = 0; /* the same value whichever thread writes it */
+        if (!static_lds) {
+            hipFuncAttributes fa;
+            HIPCHK(ctx, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k1_match_indexed<true, false>)));
+            static_lds = fa.sharedSizeBytes;
+        }
+        /* LDS is handed out in granules: five blocks get 25 of the CU's 128 each */
+        const size_t budget = (K1_CU_LDS_BYTES / K1_LDS_GRANULE / 5u) * K1_LDS_GRANULE;
+        while (static_lds + lds_bytes(str_cap) > budget && str_cap > spb * 128u)
+            str_cap -= 256u;
+    }
+    size_t lds = lds_bytes(str_cap);
     const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
 #ifdef MCX_K1_STAMPS
     if (!g_k1_stamps)

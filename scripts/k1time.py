@@ -8,6 +8,15 @@ from montecarlo_amd import Context, synth  # noqa: E402
 N, P = int(os.environ.get("K1_N", 1000)), int(os.environ.get("K1_P", 30000))
 A, a_off, a_mod = synth.alias_table(2, P)
 S, s_off = synth.modalias_strings(2, P, N)
+if os.environ.get("K1_EXTRA_LENS"):
+    # literal patterns of every length 1..33: the table then has all 33 key lengths
+    import numpy as np
+    extra = [b"zz" + b"q" * k for k in range(0, 33)]
+    blob = b"".join(extra)
+    A = np.concatenate([A, np.frombuffer(blob, dtype=np.uint8)])
+    lens = np.cumsum([len(e) for e in extra]).astype(np.uint32) + a_off[-1]
+    a_off = np.concatenate([a_off, lens]).astype(np.uint32)
+    a_mod = np.concatenate([a_mod, np.zeros(len(extra), dtype=np.uint32)]).astype(np.uint32)
 ctx = Context(0)
 ctx.alias_table_load(A, a_off, a_mod)
 dS, dO = ctx.to_device(S), ctx.to_device(s_off)
