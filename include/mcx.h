@@ -101,7 +101,8 @@ int mcx_timer_end(mcx_ctx *ctx, float *ms_out);
  * the C locale.  Supported grammar: literals, '?', '*', '\' escapes and
  * bracket expressions with literals, ranges, leading '!' or '^' and leading
  * ']'.  POSIX [:class:], [=x=] and [.x.] sub-expressions are rejected with
- * MCX_E_PATTERN (no modules.alias line uses them).
+ * MCX_E_PATTERN (no modules.alias line uses them).  At most 2^26 patterns per
+ * table (MCX_E_BAD_ARG beyond; larger tables are sharded over contexts).
  */
 int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
                          const uint32_t *a_mod, uint32_t P, uint32_t flags);
@@ -113,7 +114,10 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
  */
 int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N,
                     uint32_t *first_idx, uint32_t *count);
-/* Same with everything resident on the device; enqueues and returns. */
+/* Same with everything resident on the device; enqueues and returns.  The
+ * host-buffer call checks that s_off is non-decreasing; here the offsets are
+ * out of the host's sight and are trusted: d_s_off must hold N + 1
+ * non-decreasing offsets into d_S (4-byte aligned d_S is read by words). */
 int mcx_alias_match_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N,
                         void *d_first_idx, void *d_count);
 /*
