@@ -141,6 +141,21 @@ def test_k1_edge_cases(gpu_ctx, oracle_mod):
     assert (f == NO_MATCH).all() and (c == 0).all()
 
 
+def test_k1_table_size_limit(gpu_ctx):
+    """Survivor entries keep a pattern number in 26 bits: a larger table is refused
+    before anything is read (the arrays here hold a single pattern)."""
+    import ctypes
+
+    arena = np.frombuffer(b"x", dtype=np.uint8)
+    a_off = np.array([0, 1], dtype=np.uint32)
+    a_mod = np.zeros(1, dtype=np.uint32)
+    rc = gpu_ctx.lib.mcx_alias_table_load(
+        gpu_ctx.h, arena.ctypes.data_as(ctypes.c_void_p), a_off.ctypes.data_as(ctypes.c_void_p),
+        a_mod.ctypes.data_as(ctypes.c_void_p), (1 << 26) + 1, 0)
+    assert rc == -2  # MCX_E_BAD_ARG
+    assert b"2^26" in gpu_ctx.lib.mcx_last_error(gpu_ctx.h)
+
+
 @pytest.mark.parametrize("N", [1, 2049, 5000, 70000])
 def test_k1_single_key_length_tables(gpu_ctx, oracle_mod, N):
     """tables whose patterns all share one literal-prefix length (one probe per string), with
