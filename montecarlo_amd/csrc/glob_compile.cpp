@@ -589,5 +589,8 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         memcpy(sl.key, kw, sizeof kw);
         out.slots[at] = sl;
     }
+    out.tags.resize(cap);
+    for (size_t at = 0; at < cap; ++at)
+        out.tags[at] = out.slots[at].count ? (uint8_t)mcx_key_tag(out.slots[at].hash) : 0u;
     return 0;
 }

@@ -35,6 +35,7 @@ struct mcx_compiled_table {
     std::vector<uint32_t> ext;       /* programs too long for a slot          */
     std::vector<uint32_t> sig;       /* n_indexed gram signatures, index order */
     std::vector<mcx_slot_t> slots;   /* open-addressing hash table, 2^k slots */
+    std::vector<uint8_t> tags;       /* per slot: 0 = empty, else mcx_key_tag of the key's hash */
     std::vector<uint32_t> lens;      /* distinct key lengths, ascending       */
     std::vector<uint32_t> sets;      /* distinct bracket sets, 8 words each   */
     std::map<std::array<uint32_t, 8>, uint32_t> set_ids; /* set bits -> number */

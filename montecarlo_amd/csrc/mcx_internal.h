@@ -37,6 +37,7 @@ struct mcx_ctx {
     uint32_t *d_dup_idx = nullptr;   /* table positions of repeated pattern texts */
     uint32_t *d_lens = nullptr;      /* nlens distinct key lengths             */
     mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
+    uint8_t *d_tags = nullptr;       /* one tag byte per index slot            */
     uint32_t slot_mask = 0;
     uint32_t nlens = 0;
     uint32_t *d_sets = nullptr;

@@ -39,6 +39,7 @@ struct k1_table_t {
     const uint32_t *ext;    /* overflow bodies                                 */
     const uint32_t *sig;    /* n_indexed gram signatures                       */
     const mcx_slot_t *slots;
+    const uint8_t *tags;    /* per index slot: 0 = empty, else mcx_key_tag(hash)  */
     const uint32_t *sets;
     const uint32_t *lens;   /* nlens key lengths                               */
     uint32_t slot_mask;
@@ -400,7 +401,18 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 #ifdef MCX_K1_STAMPS
         pt1 = __builtin_amdgcn_s_memtime();
 #endif
+        [[maybe_unused]] const uint32_t my_tag = mcx_key_tag(a);
         for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
+            if constexpr (BULK) {
+                /* most probes end at an empty slot: a large batch asks the tag bytes (which
+                 * stay in L2) first and spares itself the 64-byte entry; a small batch would
+                 * only lengthen its chain of dependent loads */
+                const uint32_t tag = T.tags[at];
+                if (tag == 0u)
+                    break;
+                if (tag != my_tag)
+                    continue;
+            }
             const mcx_slot_t sl = T.slots[at];
             if (sl.count == 0u)
                 break;
@@ -875,6 +887,7 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
         (rc = mcx_dev_upload(ctx, &ctx->d_dup_start, t.dup_start.data(), t.dup_start.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_dup_idx, t.dup_idx.data(), t.dup_idx.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_slots, t.slots.data(), t.slots.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_tags, t.tags.data(), t.tags.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_sets, t.sets.data(), t.sets.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_amod, a_mod, (size_t)P)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_hwtag, t.hw_tag.data(), t.hw_tag.size())) != 0) {
@@ -889,7 +902,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
     ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.sets.size() + t.lens.size() +
                                       t.dup_start.size() + t.dup_idx.size()) +
-                       sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + 4 * (uint64_t)P + t.hw_tag.size();
+                       sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + t.tags.size() + 4 * (uint64_t)P +
+                       t.hw_tag.size();
     ctx->table_loaded = true;
     return MCX_OK;
 }
@@ -941,6 +955,7 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     T.sig = ctx->d_sig;
     T.lens = ctx->d_lens;
     T.slots = ctx->d_slots;
+    T.tags = ctx->d_tags;
     T.sets = ctx->d_sets;
     T.slot_mask = ctx->slot_mask;
     T.nlens = ctx->nlens;

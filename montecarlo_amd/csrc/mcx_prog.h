@@ -119,6 +119,13 @@ typedef struct {
     uint32_t pad[4];
 } mcx_slot_t;
 
+/* One byte per index slot, read before the 64-byte entry where misses are the
+ * rule: 0 marks an empty slot, anything else is this function of the key's hash. */
+MCX_HD uint32_t mcx_key_tag(uint32_t hash)
+{
+    return 1u + (hash >> 24) % 255u;
+}
+
 /* Hash of a key of `len` <= MCX_KEY_MAX bytes held in little-endian words
  * kw[0..7] (bytes past `len` must be zero).  It only spreads the keys over the
  * table: a probe compares the key itself. */
