@@ -39,6 +39,8 @@ def oracle():
         lib.orc_alias_match.argtypes = [_vp, _vp, u32, _vp, _vp, u32, u32, ctypes.c_int, _vp, _vp]
         lib.orc_dep_flags.restype = None
         lib.orc_dep_flags.argtypes = [_vp, _vp, u32, _vp, _vp, _vp]
+        lib.orc_dep_flags_pull.restype = None
+        lib.orc_dep_flags_pull.argtypes = [_vp, _vp, _vp, _vp, _vp, u32, u32]
         lib.orc_dep_closure.restype = u64
         lib.orc_dep_closure.argtypes = [_vp, _vp, u32, u32, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(u32)]
         lib.orc_safe_name.restype = ctypes.c_int
@@ -125,6 +127,52 @@ def dep_flags(rowptr, col, in_flags):
     out = np.zeros(max(V, 1), dtype=np.uint8)
     ref = np.zeros(max(V, 1), dtype=np.uint32)
     oracle().orc_dep_flags(_p(rowptr), _p(_c(col, np.uint32)), V, _p(_c(in_flags, np.uint8)), _p(out), _p(ref))
+    return out[:V], ref[:V]
+
+
+def holders_graph(rowptr, col):
+    """(rrow, rcol): module v is held by rcol[rrow[v] .. rrow[v+1]), holders ascending"""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
+    col = np.ascontiguousarray(col, dtype=np.uint32)
+    V = len(rowptr) - 1
+    src = np.repeat(np.arange(V, dtype=np.uint32), np.diff(rowptr.astype(np.int64)))
+    rcol = np.ascontiguousarray(src[np.argsort(col, kind="stable")])
+    rrow = np.zeros(V + 1, dtype=np.uint32)
+    rrow[1:] = np.cumsum(np.bincount(col, minlength=V), dtype=np.uint64).astype(np.uint32)
+    return rrow, rcol
+
+
+def holders_cut(rrow, threads):
+    """module ranges with equal shares of edges + modules, so that neither a hub nor a
+    run of leaves makes a long range; a property of the graph, computed once"""
+    V, E = len(rrow) - 1, int(rrow[-1])
+    work = np.asarray(rrow, dtype=np.int64) + np.arange(V + 1, dtype=np.int64)
+    cut = np.searchsorted(work, [(E + V) * t // threads for t in range(threads + 1)], side="left")
+    cut[0], cut[-1] = 0, V
+    return [int(c) for c in cut]
+
+
+def dep_flags_threads(rrow, rcol, in_flags, threads, pool=None, cut=None):
+    """dep_flags by `threads` threads over the graph of holders (holders_graph), every
+    thread owning one range of holders_cut.  pool: a ThreadPoolExecutor to reuse (one is
+    made and dropped otherwise)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    rrow = np.ascontiguousarray(rrow, dtype=np.uint32)
+    rcol, in_flags = _c(rcol, np.uint32), _c(in_flags, np.uint8)
+    V = len(rrow) - 1
+    out = np.empty(max(V, 1), dtype=np.uint8)
+    ref = np.empty(max(V, 1), dtype=np.uint32)
+    cut = cut or holders_cut(rrow, threads)
+    lib = oracle()
+    own = pool is None
+    pool = pool or ThreadPoolExecutor(max_workers=threads)
+    try:
+        list(pool.map(lambda t: lib.orc_dep_flags_pull(_p(rrow), _p(rcol), _p(in_flags), _p(out), _p(ref),
+                                                       cut[t], cut[t + 1]), range(threads)))
+    finally:
+        if own:
+            pool.shutdown()
     return out[:V], ref[:V]
 
 

@@ -197,6 +197,36 @@ void orc_dep_flags(const uint32_t *rowptr, const uint32_t *col, uint32_t V,
 }
 
 /*
+ * The same flags from several threads (the edge-parallel form of the CPU
+ * baseline).  Counting into the held module from the holder's side needs an
+ * atomic increment per edge, and the few modules everything depends on make
+ * those collide (measured: slower than one thread); so this form pulls: given
+ * the graph of holders (rrow/rcol: v is held by rcol[rrow[v] .. rrow[v+1]),
+ * built once like the device's copy), every caller owns the modules [v0, v1).
+ */
+void orc_dep_flags_pull(const uint32_t *rrow, const uint32_t *rcol, const uint8_t *in_flags,
+                        uint8_t *out_flags, uint32_t *refcnt, uint32_t v0, uint32_t v1)
+{
+    for (uint32_t v = v0; v < v1; ++v) {
+        uint8_t f = in_flags[v], o = 0;
+        uint32_t holders = 0;
+        if (f & F_LOADED) {
+            for (uint32_t k = rrow[v]; k < rrow[v + 1]; ++k)
+                holders += in_flags[rcol[k]] & F_LOADED;
+            if (holders)
+                o |= O_HAS_HOLDERS;
+            if ((f & F_BOUND) || holders)
+                o |= O_IN_USE;
+            if ((f & F_SAFE) && !holders)
+                o |= O_ROOT;
+        }
+        out_flags[v] = o;
+        if (refcnt)
+            refcnt[v] = (f & F_LOADED) ? holders + ((f & F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
+    }
+}
+
+/*
  * direction 0: out = loaded modules from which a loaded seed is reachable
  * along "needs" edges through loaded modules only (the modules that must go
  * before the seeds can be unloaded, the condition the reference reports at

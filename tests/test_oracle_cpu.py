@@ -280,6 +280,20 @@ def test_dep_oracle_against_bruteforce(oracle_mod, seed, V, deg):
         assert levels >= 1 and scanned >= 0
 
 
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_dep_flags_threaded_baseline_equals_sequential(oracle_mod, threads):
+    """The edge-parallel form of the CPU baseline (several threads, each counting the
+    loaded holders of its own modules) gives the sequential scan's bytes, also on
+    empty and tiny graphs."""
+    for seed, V, deg in [(5, 20000, 9), (6, 7, 2), (7, 1, 1)]:
+        rowptr, col = synth.dep_graph(seed, V, deg)
+        flags = synth.dep_flags(seed, rowptr, col, 150)
+        out, ref = oracle_mod.dep_flags(rowptr, col, flags)
+        rrow, rcol = oracle_mod.holders_graph(rowptr, col)
+        out_t, ref_t = oracle_mod.dep_flags_threads(rrow, rcol, flags, threads)
+        assert np.array_equal(out, out_t) and np.array_equal(ref, ref_t)
+
+
 def test_dep_oracle_hand_graphs(oracle_mod):
     # chain 3 -> 2 -> 1 -> 0 ("u needs v"), all loaded
     rowptr = np.array([0, 0, 1, 2, 3], dtype=np.uint32)
