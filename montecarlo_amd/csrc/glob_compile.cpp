@@ -477,6 +477,28 @@ static uint32_t sig_of(const mcx_pattern_ir &ir, size_t keylen)
     }
     return sig;
 }
+
+/* the distinct four-literal windows of the pattern that are not wholly inside
+ * the index key: every string the pattern matches holds each of them */
+static std::vector<uint32_t> grams_of(const mcx_pattern_ir &ir, size_t keylen)
+{
+    std::vector<uint32_t> out;
+    for (size_t si = 0; si < ir.segs.size(); ++si) {
+        const auto &sg = ir.segs[si];
+        for (size_t k = 0; k + 4 <= sg.size(); ++k) {
+            if (sg[k].kind != M_LIT || sg[k + 1].kind != M_LIT || sg[k + 2].kind != M_LIT ||
+                sg[k + 3].kind != M_LIT)
+                continue;
+            if (si == 0 && k + 4 <= keylen)
+                continue;
+            uint32_t g = (uint32_t)sg[k].byte | ((uint32_t)sg[k + 1].byte << 8) |
+                         ((uint32_t)sg[k + 2].byte << 16) | ((uint32_t)sg[k + 3].byte << 24);
+            if (std::find(out.begin(), out.end(), g) == out.end())
+                out.push_back(g);
+        }
+    }
+    return out;
+}
 } // namespace
 
 int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
@@ -537,6 +559,75 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     });
     size_t n_idx = order.size();
     out.n_distinct = (uint32_t)n_idx;
+    /* large groups: every pattern picks the rarest of its grams within the group as
+     * its anchor; the group is reordered (no anchor first, then by anchor gram, then
+     * by table position) and the runs are remembered for the second index */
+    struct SubRun {
+        uint32_t gram, gid, start, count;
+    };
+    struct SubGroup {
+        uint32_t gid, rest;
+    };
+    /* test seam: MCX_SUB_MIN in the environment moves the size from which a group gets a
+     * second index (tests set it low so that small tables exercise that path) */
+    const char *sub_env = getenv("MCX_SUB_MIN");
+    const size_t sub_min = sub_env && *sub_env ? (size_t)strtoul(sub_env, nullptr, 10) : (size_t)MCX_SUB_MIN;
+    std::vector<SubRun> sub_runs;
+    std::unordered_map<uint32_t, SubGroup> sub_groups; /* by group start */
+    for (size_t g0 = 0; g0 < n_idx;) {
+        size_t g1 = g0 + 1;
+        while (g1 < n_idx && keys[order[g1]] == keys[order[g0]])
+            ++g1;
+        if (g1 - g0 > sub_min) {
+            const size_t keylen = keys[order[g0]].size();
+            std::vector<std::vector<uint32_t>> cand(g1 - g0);
+            std::unordered_map<uint32_t, uint32_t> freq;
+            for (size_t k = g0; k < g1; ++k) {
+                cand[k - g0] = grams_of(irs[order[k]], keylen);
+                for (uint32_t g : cand[k - g0])
+                    freq[g]++;
+            }
+            struct Item {
+                uint32_t j, has, gram;
+            };
+            std::vector<Item> items(g1 - g0);
+            for (size_t k = g0; k < g1; ++k) {
+                Item it{order[k], 0u, 0u};
+                uint32_t best = 0xFFFFFFFFu;
+                for (uint32_t g : cand[k - g0]) {
+                    const uint32_t f = freq[g];
+                    if (f < best || (f == best && g < it.gram)) {
+                        best = f;
+                        it.gram = g;
+                        it.has = 1u;
+                    }
+                }
+                items[k - g0] = it;
+            }
+            std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) {
+                if (x.has != y.has)
+                    return x.has < y.has;
+                if (x.gram != y.gram)
+                    return x.gram < y.gram;
+                return x.j < y.j;
+            });
+            const uint32_t gid = out.n_sub_groups++;
+            uint32_t rest = 0;
+            for (size_t k = g0; k < g1; ++k) {
+                const Item &it = items[k - g0];
+                order[k] = it.j;
+                if (!it.has) {
+                    ++rest;
+                    continue;
+                }
+                if (sub_runs.empty() || sub_runs.back().gid != gid || sub_runs.back().gram != it.gram)
+                    sub_runs.push_back(SubRun{it.gram, gid, (uint32_t)k, 0u});
+                sub_runs.back().count++;
+            }
+            sub_groups[(uint32_t)g0] = SubGroup{gid, rest};
+        }
+        g0 = g1;
+    }
     out.slot.assign(n_idx * (size_t)MCX_SLOT_WORDS, 0u);
     out.sig.resize(n_idx);
     out.dup_start.assign(n_idx ? n_idx : 1, 0u);
@@ -587,10 +678,29 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
             at = (at + 1) & (cap - 1);
         mcx_slot_t sl = mcx_slot_t{a, (uint32_t)key.size(), g.start, g.count, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}};
         memcpy(sl.key, kw, sizeof kw);
+        auto sg = sub_groups.find(g.start);
+        if (sg != sub_groups.end()) {
+            sl.pad[0] = sg->second.gid + 1u;
+            sl.pad[1] = sg->second.rest;
+        }
         out.slots[at] = sl;
     }
     out.tags.resize(cap);
     for (size_t at = 0; at < cap; ++at)
         out.tags[at] = out.slots[at].count ? (uint8_t)mcx_key_tag(out.slots[at].hash) : 0u;
+    /* second index, never empty, one entry in four used */
+    size_t scap = 16;
+    while (scap < 4 * sub_runs.size())
+        scap *= 2;
+    out.sub.assign(scap, mcx_sub_t{0, 0, 0, 0});
+    out.sub_tags.assign(scap, 0u);
+    for (const SubRun &r : sub_runs) {
+        const uint32_t h = mcx_sub_hash(r.gram, r.gid);
+        size_t at = h & (scap - 1);
+        while (out.sub[at].count != 0)
+            at = (at + 1) & (scap - 1);
+        out.sub[at] = mcx_sub_t{r.gram, r.gid, r.start, r.count};
+        out.sub_tags[at] = (uint8_t)mcx_key_tag(h);
+    }
     return 0;
 }

@@ -36,6 +36,9 @@ struct mcx_compiled_table {
     std::vector<uint32_t> sig;       /* n_indexed gram signatures, index order */
     std::vector<mcx_slot_t> slots;   /* open-addressing hash table, 2^k slots */
     std::vector<uint8_t> tags;       /* per slot: 0 = empty, else mcx_key_tag of the key's hash */
+    std::vector<mcx_sub_t> sub;      /* (large group, anchor gram) -> run of patterns, 2^k entries */
+    std::vector<uint8_t> sub_tags;   /* per entry of sub: 0 = empty, else mcx_key_tag of its hash */
+    uint32_t n_sub_groups = 0;       /* groups that have a second index        */
     std::vector<uint32_t> lens;      /* distinct key lengths, ascending       */
     std::vector<uint32_t> sets;      /* distinct bracket sets, 8 words each   */
     std::map<std::array<uint32_t, 8>, uint32_t> set_ids; /* set bits -> number */

@@ -19,6 +19,8 @@ void mcx_free_table(mcx_ctx *ctx)
     (void)hipFree(ctx->d_lens);
     (void)hipFree(ctx->d_slots);
     (void)hipFree(ctx->d_tags);
+    (void)hipFree(ctx->d_sub);
+    (void)hipFree(ctx->d_sub_tags);
     (void)hipFree(ctx->d_sets);
     (void)hipFree(ctx->d_amod);
     (void)hipFree(ctx->d_hwtag);
@@ -31,6 +33,8 @@ void mcx_free_table(mcx_ctx *ctx)
     ctx->d_lens = nullptr;
     ctx->d_slots = nullptr;
     ctx->d_tags = nullptr;
+    ctx->d_sub = nullptr;
+    ctx->d_sub_tags = nullptr;
     ctx->d_sets = nullptr;
     ctx->d_amod = nullptr;
     ctx->d_hwtag = nullptr;

@@ -38,6 +38,9 @@ struct mcx_ctx {
     uint32_t *d_lens = nullptr;      /* nlens distinct key lengths             */
     mcx_slot_t *d_slots = nullptr;   /* prefix index                           */
     uint8_t *d_tags = nullptr;       /* one tag byte per index slot            */
+    mcx_sub_t *d_sub = nullptr;      /* second index of the large groups       */
+    uint8_t *d_sub_tags = nullptr;
+    uint32_t sub_mask = 0, n_sub_groups = 0;
     uint32_t slot_mask = 0;
     uint32_t nlens = 0;
     uint32_t *d_sets = nullptr;

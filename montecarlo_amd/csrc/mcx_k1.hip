@@ -25,7 +25,10 @@
 #define K1_MAX_PATTERNS (1u << 26) /* survivor entries and group counts keep a pattern number in 26 bits */
 #define K1_CU_LDS_BYTES 163840u /* LDS of one gfx950 CU */
 #define K1_LDS_GRANULE 1280u    /* ... allocated to blocks in pieces of this size */
-#define K1_QUARTER 64u      /* a group of at most this many patterns takes a quarter of a
+#define K1_QUARTER 64u
+#define K1_LANEMAP 512u  /* screening lanes the small groups of one block can take */
+#define K1_BIGLIST 32u   /* (string, large group) pairs of one block that go through the second index */
+#define K1_LANE_NONE 0xFFFFu      /* a group of at most this many patterns takes a quarter of a
                                step (16 lanes): four such groups share one          */
 #define K1_GROUP 16u        /* survivors one wave stages per pass                 */
 #define K1_SUB 8u           /* of which it runs eight at a time, eight lanes each */
@@ -40,6 +43,9 @@ struct k1_table_t {
     const uint32_t *sig;    /* n_indexed gram signatures                       */
     const mcx_slot_t *slots;
     const uint8_t *tags;    /* per index slot: 0 = empty, else mcx_key_tag(hash)  */
+    const mcx_sub_t *sub;   /* second index of the large groups                 */
+    const uint8_t *sub_tags;
+    uint32_t sub_mask;
     const uint32_t *sets;
     const uint32_t *lens;   /* nlens key lengths                               */
     uint32_t slot_mask;
@@ -237,7 +243,8 @@ __device__ __attribute__((noinline)) void k1_normalize_tile(uint32_t *str_w, con
 template <bool BULK, bool LIST>
 __global__ void __launch_bounds__(K1_THREADS, 4)
 k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
-                 uint32_t str_cap, uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
+                 uint32_t str_cap, uint32_t s_aligned, uint32_t sub_cap, const k1_table_t T,
+                 uint32_t *__restrict__ first_idx,
                  uint32_t *__restrict__ count, const k1_list_t L
 #ifdef MCX_K1_STAMPS
                  , unsigned long long *__restrict__ stamps
@@ -262,8 +269,9 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     K1_STAMP(0);
     /* dynamic LDS, sized by the launch for its strings-per-block:
      * [spb occurrence tables][str_cap/4 + 5 words of string bytes]
-     * [hit_start][hit_cnt][hit_ub][qhit], max_hits words each (hit_cnt: pattern
-     * count in bits 0..25, string slot above) */
+     * [hit_start][hit_cnt] of max_hits + sub_cap words each (hit_cnt: pattern
+     * count in bits 0..25, string slot above; the last sub_cap entries are the
+     * runs found through the second index), [hit_ub] of max_hits words */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
     /* survivors waiting for a program run.  A round adds at most K1_WAVES x K1_UNIT and leaves
      * less than K1_WAVES x GROUP behind; large batches take the smaller ring so that five
@@ -279,14 +287,21 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     __shared__ uint32_t res_first[K1_MAX_SPB], res_count[K1_MAX_SPB];
     __shared__ uint32_t str_at[K1_MAX_SPB], str_len[K1_MAX_SPB], refused[K1_MAX_SPB];
     __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
-    __shared__ uint32_t nhits, nunits_sh, nq_sh, ring_cum[2];
+    __shared__ uint32_t nhits, nunits_sh, ring_cum[2];
     const uint32_t max_hits = spb * T.nlens;
     uint32_t *occ_w = k1_lds;
     uint32_t *str_w = occ_w + spb * K1_OCC_WORDS;
     uint32_t *hit_start = str_w + str_cap / 4u + 5u;
-    uint32_t *hit_cnt = hit_start + max_hits;
-    uint32_t *hit_ub = hit_cnt + max_hits;
-    uint32_t *qhit = hit_ub + max_hits; /* small groups in order of arrival: their hit numbers */
+    uint32_t *hit_cnt = hit_start + max_hits + sub_cap;
+    uint32_t *hit_ub = hit_cnt + max_hits + sub_cap;
+    /* small groups (at most K1_QUARTER patterns) share screening steps: each takes one
+     * lane per four patterns; lane_map[g] = hit number << 4 | which four */
+    __shared__ uint16_t lane_map[K1_LANEMAP];
+    /* (string, large group) pairs: string slot | group number << 3, and the group's
+     * first pattern, size and number of patterns without an anchor gram */
+    __shared__ uint32_t big_slot[BULK ? K1_BIGLIST : 1u], big_start[BULK ? K1_BIGLIST : 1u],
+        big_count[BULK ? K1_BIGLIST : 1u], big_rest[BULK ? K1_BIGLIST : 1u];
+    __shared__ uint32_t nlanes_sh, nbiglist_sh, nsub_sh;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -324,7 +339,9 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     if (tid == 0) {
         nhits = 0;
         nunits_sh = 0;
-        nq_sh = 0;
+        nlanes_sh = 0;
+        nbiglist_sh = 0;
+        nsub_sh = 0;
         ring_cum[0] = 0;
         ring_cum[1] = 0;
     }
@@ -369,6 +386,36 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
 
     K1_STAMP(3);
+    /* one lane records a group of candidates (a hit) for string `slot`: a large group
+     * takes units of its own, a small one lanes of the shared units */
+    auto emit_hit = [&](uint32_t start, uint32_t cnt, uint32_t slot) __attribute__((always_inline)) {
+        const uint32_t h = atomicAdd(&nhits, 1u);
+        hit_start[h] = start;
+        hit_cnt[h] = cnt | (slot << 26);
+        uint32_t ub = 0xFFFFFFFFu;
+        if (cnt > K1_QUARTER) {
+            /* the group's units take the next free places of the block's unit
+             * space, in whatever order the hits arrive */
+            ub = atomicAdd(&nunits_sh, (cnt + K1_UNIT - 1u) / K1_UNIT);
+        } else if constexpr (!BULK) {
+            /* small batches: a quarter of a shared unit per small group, whatever its
+             * size; lane_map is then the list of their hit numbers (one write here,
+             * on the block's critical path) */
+            lane_map[atomicAdd(&nlanes_sh, 1u)] = (uint16_t)h;
+        } else {
+            const uint32_t nl = (cnt + 3u) / 4u, lb = atomicAdd(&nlanes_sh, nl);
+            if (lb + nl <= K1_LANEMAP) {
+                for (uint32_t t = 0; t < nl; ++t)
+                    lane_map[lb + t] = (uint16_t)((h << 4) | t);
+            } else {
+                /* the shared units are full: a unit of its own after all */
+                for (uint32_t g = lb; g < K1_LANEMAP; ++g)
+                    lane_map[g] = (uint16_t)K1_LANE_NONE;
+                ub = atomicAdd(&nunits_sh, 1u);
+            }
+        }
+        hit_ub[h] = ub;
+    };
     /* ---- probe: last wave first, so that it overlaps the gram sets -------- */
 #ifdef MCX_K1_STAMPS
     unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pt1 = pt0, pt2 = pt0;
@@ -421,19 +468,22 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
                 same = same && sl.key[k] == kw[k];
             if (same) {
-                /* the group's units take the next free places of the block's
-                 * unit space, in whatever order the hits arrive */
-                const uint32_t units = (sl.count + K1_UNIT - 1u) / K1_UNIT;
-                const uint32_t h = atomicAdd(&nhits, 1u);
-                if (sl.count > K1_QUARTER) {
-                    hit_ub[h] = atomicAdd(&nunits_sh, units);
-                } else {
-                    /* a small group: a quarter of one of the units behind the large groups' */
-                    qhit[atomicAdd(&nq_sh, 1u)] = h;
-                    hit_ub[h] = 0xFFFFFFFFu;
+                bool listed = false;
+                if constexpr (BULK) {
+                    /* a group with a second index: looked up by the string's grams below */
+                    if (sl.pad[0] != 0u && sub_cap != 0u && use_lds && len <= MCX_OCC_MAX_LEN) {
+                        const uint32_t bi = atomicAdd(&nbiglist_sh, 1u);
+                        if (bi < K1_BIGLIST) {
+                            big_slot[bi] = slot | ((sl.pad[0] - 1u) << 3);
+                            big_start[bi] = sl.start;
+                            big_count[bi] = sl.count;
+                            big_rest[bi] = sl.pad[1];
+                            listed = true;
+                        }
+                    }
                 }
-                hit_start[h] = sl.start;
-                hit_cnt[h] = sl.count | (slot << 26);
+                if (!listed)
+                    emit_hit(sl.start, sl.count, slot);
                 break;
             }
         }
@@ -446,12 +496,119 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
 #endif
     __syncthreads();
+    if constexpr (BULK) {
+        K1_STAMP(7);
+        /* ---- large groups through their second index: a wave per (string, group),
+         * a lane per four-byte window of the string.  Every pattern of the group
+         * outside its head names a gram it needs; the runs of the grams the string
+         * holds are the only candidates, and they come as small groups.  When the
+         * block's room for them is used up the whole group is screened instead. */
+        const uint32_t nb = min(nbiglist_sh, K1_BIGLIST);
+        /* what happens to one pair once its lanes know their runs */
+        auto sub_finish = [&](uint32_t slot, uint32_t gstart, uint32_t gcount, uint32_t rest, bool found,
+                              uint32_t fstart, uint32_t fcnt) __attribute__((always_inline)) {
+            /* a gram that occurs twice in the string names its run once; the runs get
+             * consecutive entries (64 patterns each) and lanes (four patterns each) */
+            const uint32_t pieces = (fcnt + K1_QUARTER - 1u) / K1_QUARTER, nl = (fcnt + 3u) / 4u;
+            uint32_t my_e = 0, my_l = 0, tot_e = 0, tot_l = 0;
+            unsigned long long todo = __ballot(found);
+            while (todo) {
+                const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(todo));
+                const uint32_t s = __builtin_amdgcn_readlane(fstart, l);
+                const bool same = found && fstart == s;
+                const unsigned long long sm = __ballot(same);
+                if (same && lane != l)
+                    found = false;
+                if (lane == l) {
+                    my_e = tot_e;
+                    my_l = tot_l;
+                }
+                tot_e += __builtin_amdgcn_readlane(pieces, l);
+                tot_l += __builtin_amdgcn_readlane(nl, l);
+                todo &= ~sm;
+            }
+            uint32_t ebase = 0, lbase = 0;
+            if (lane == 0) {
+                ebase = atomicAdd(&nsub_sh, tot_e);
+                lbase = atomicAdd(&nlanes_sh, tot_l);
+            }
+            ebase = __builtin_amdgcn_readfirstlane(ebase);
+            lbase = __builtin_amdgcn_readfirstlane(lbase);
+            if (ebase + tot_e <= sub_cap && lbase + tot_l <= K1_LANEMAP) {
+                if (lane == 0 && rest != 0u)
+                    emit_hit(gstart, rest, slot);
+                if (found) {
+                    for (uint32_t i = 0; i < pieces; ++i) {
+                        const uint32_t h = max_hits + ebase + my_e + i;
+                        const uint32_t c = min(K1_QUARTER, fcnt - K1_QUARTER * i);
+                        hit_start[h] = fstart + K1_QUARTER * i;
+                        hit_cnt[h] = c | (slot << 26);
+                        for (uint32_t t = 0; t < (c + 3u) / 4u; ++t)
+                            lane_map[lbase + my_l + 16u * i + t] = (uint16_t)((h << 4) | t);
+                    }
+                }
+            } else {
+                /* no room: give back nothing (later pairs fail the same way), blank the
+                 * lanes that were taken and screen the whole group */
+                const uint32_t gend = lbase + tot_l < K1_LANEMAP ? lbase + tot_l : K1_LANEMAP;
+                for (uint32_t g = lbase + lane; g < gend; g += 64u)
+                    lane_map[g] = (uint16_t)K1_LANE_NONE;
+                if (lane == 0)
+                    emit_hit(gstart, gcount, slot);
+            }
+        };
+        /* two pairs a wave at a time: the first tag is asked for both before either is used */
+        for (uint32_t b0 = wave; b0 < nb; b0 += 2u * K1_WAVES) {
+            uint32_t w[2] = {0, 0}, gid[2] = {0, 0}, at[2] = {0, 0}, tag[2] = {0, 0};
+            bool act[2];
+#pragma unroll
+            for (uint32_t i = 0; i < 2u; ++i) {
+                const uint32_t b = b0 + i * K1_WAVES;
+                act[i] = false;
+                if (b < nb) {
+                    const uint32_t slot = big_slot[b] & 7u;
+                    gid[i] = big_slot[b] >> 3;
+                    if (lane + 4u <= str_len[slot]) {
+                        act[i] = true;
+                        w[i] = LdsStr{(lds_words_t)str_w, str_at[slot]}.word(lane);
+                        at[i] = mcx_sub_hash(w[i], gid[i]);
+                        tag[i] = T.sub_tags[at[i] & T.sub_mask];
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 2u; ++i) {
+                const uint32_t b = b0 + i * K1_WAVES;
+                if (b >= nb)
+                    break;
+                bool found = false;
+                uint32_t fstart = 0, fcnt = 0;
+                if (act[i]) {
+                    const uint32_t tg = mcx_key_tag(at[i]);
+                    uint32_t t = tag[i];
+                    for (uint32_t p = at[i] & T.sub_mask; t != 0u; p = (p + 1u) & T.sub_mask, t = T.sub_tags[p]) {
+                        if (t != tg)
+                            continue;
+                        const mcx_sub_t e = T.sub[p];
+                        if (e.gram == w[i] && e.gid == gid[i]) {
+                            found = true;
+                            fstart = e.start;
+                            fcnt = e.count;
+                            break;
+                        }
+                    }
+                }
+                sub_finish(big_slot[b] & 7u, big_start[b], big_count[b], big_rest[b], found, fstart, fcnt);
+            }
+        }
+        __syncthreads();
+    }
     K1_STAMP(2);
 
     /* ---- units -> survivors ----------------------------------------------- */
     const uint32_t nh = nhits;
-    const uint32_t nbig = nunits_sh, nq = nq_sh;
-    const uint32_t nunits = nbig + (nq + 3u) / 4u;
+    const uint32_t nbig = nunits_sh, nlanes = min(nlanes_sh, K1_LANEMAP);
+    const uint32_t nunits = nbig + (BULK ? (nlanes + 63u) / 64u : (nlanes + 3u) / 4u);
     /* the first 64 hits live in registers, one per lane */
     uint32_t my_ub = 0, my_units = 0, my_start = 0, my_cnt = 0, my_slot = 0;
     if (lane < nh) {
@@ -463,18 +620,30 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     /* unit u -> per lane: first of its four patterns, how many of the four exist, string slot.
      * Units below nbig are 256 consecutive patterns of one large group; the ones
-     * behind them hold four small groups, one per 16 lanes. */
+     * behind them hold small groups: a lane per four patterns (large batches)
+     * or a quarter of the unit per group (small batches). */
     auto unit_at = [&](uint32_t u, uint32_t &pk, uint32_t &pn, uint32_t &pslot) __attribute__((always_inline)) {
         if (u >= nbig) {
-            const uint32_t q = 4u * (u - nbig) + (lane >> 4), sub = 4u * (lane & 15u);
             pk = 0;
             pn = 0;
             pslot = 0;
-            if (q < nq) {
-                const uint32_t h = qhit[q], cs = hit_cnt[h], cnt = cs & 0x03FFFFFFu;
-                pk = hit_start[h] + sub;
-                pn = cnt > sub ? min(4u, cnt - sub) : 0u;
-                pslot = cs >> 26;
+            if constexpr (BULK) {
+                const uint32_t g = 64u * (u - nbig) + lane;
+                const uint32_t e = g < nlanes ? lane_map[g] : K1_LANE_NONE;
+                if (e != K1_LANE_NONE) {
+                    const uint32_t h = e >> 4, sub = 4u * (e & 15u), cs = hit_cnt[h], cnt = cs & 0x03FFFFFFu;
+                    pk = hit_start[h] + sub;
+                    pn = min(4u, cnt - sub);
+                    pslot = cs >> 26;
+                }
+            } else {
+                const uint32_t q = 4u * (u - nbig) + (lane >> 4), sub = 4u * (lane & 15u);
+                if (q < nlanes) {
+                    const uint32_t h = lane_map[q], cs = hit_cnt[h], cnt = cs & 0x03FFFFFFu;
+                    pk = hit_start[h] + sub;
+                    pn = cnt > sub ? min(4u, cnt - sub) : 0u;
+                    pslot = cs >> 26;
+                }
             }
             return;
         }
@@ -888,6 +1057,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
         (rc = mcx_dev_upload(ctx, &ctx->d_dup_idx, t.dup_idx.data(), t.dup_idx.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_slots, t.slots.data(), t.slots.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_tags, t.tags.data(), t.tags.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_sub, t.sub.data(), t.sub.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_sub_tags, t.sub_tags.data(), t.sub_tags.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_sets, t.sets.data(), t.sets.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_amod, a_mod, (size_t)P)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_hwtag, t.hw_tag.data(), t.hw_tag.size())) != 0) {
@@ -898,11 +1069,14 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     ctx->P = P;
     ctx->n_indexed = t.n_distinct;
     ctx->slot_mask = (uint32_t)t.slots.size() - 1u;
+    ctx->sub_mask = (uint32_t)t.sub.size() - 1u;
+    ctx->n_sub_groups = t.n_sub_groups;
     ctx->nlens = (uint32_t)t.lens.size();
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
     ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.sets.size() + t.lens.size() +
                                       t.dup_start.size() + t.dup_idx.size()) +
-                       sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + t.tags.size() + 4 * (uint64_t)P +
+                       sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + t.tags.size() +
+                       sizeof(mcx_sub_t) * (uint64_t)t.sub.size() + t.sub_tags.size() + 4 * (uint64_t)P +
                        t.hw_tag.size();
     ctx->table_loaded = true;
     return MCX_OK;
@@ -956,6 +1130,9 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     T.lens = ctx->d_lens;
     T.slots = ctx->d_slots;
     T.tags = ctx->d_tags;
+    T.sub = ctx->d_sub;
+    T.sub_tags = ctx->d_sub_tags;
+    T.sub_mask = ctx->sub_mask;
     T.sets = ctx->d_sets;
     T.slot_mask = ctx->slot_mask;
     T.nlens = ctx->nlens;
@@ -973,8 +1150,9 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
      * has larger hit arrays; the staging buffer then gives way (down to 128 bytes per string)
      * so that the fifth block still fits. */
     const bool bulk = N >= 65536u;
-    auto lds_bytes = [&](uint32_t cap) {
-        return 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)cap / 4 + 5 + 4 * (size_t)spb * T.nlens + 1);
+    uint32_t sub_cap = 0; /* entries for the runs found through the second index (large batches) */
+    auto lds_bytes = [&](uint32_t cap, uint32_t subs) {
+        return 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)cap / 4 + 5 + 3 * (size_t)spb * T.nlens + 2 * (size_t)subs + 1);
     };
     if (bulk) {
         static size_t static_lds = 0; /* the same value whichever thread writes it */
@@ -985,18 +1163,32 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         }
         /* LDS is handed out in granules: five blocks get 25 of the CU's 128 each */
         const size_t budget = (K1_CU_LDS_BYTES / K1_LDS_GRANULE / 5u) * K1_LDS_GRANULE;
-        while (static_lds + lds_bytes(str_cap) > budget && str_cap > spb * 128u)
+        const uint32_t want = ctx->n_sub_groups ? 64u : 0u; /* the least that makes the second index worth it */
+        while (static_lds + lds_bytes(str_cap, want) > budget && str_cap > spb * 128u)
             str_cap -= 256u;
+        if (want && static_lds + lds_bytes(str_cap, want) <= budget) {
+            sub_cap = (uint32_t)((budget - static_lds - lds_bytes(str_cap, 0)) / 8u);
+            if (sub_cap > 192u)
+                sub_cap = 192u;
+        }
     }
-    size_t lds = lds_bytes(str_cap);
+    size_t lds = lds_bytes(str_cap, sub_cap);
     const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
 #ifdef MCX_K1_STAMPS
-    if (!g_k1_stamps)
-        (void)hipMalloc((void **)&g_k1_stamps, 16u * 8u * 65536u);
-    g_k1_stamp_blocks = blocks < 65536u ? blocks : 65536u;
-    k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned,
-                                                                             T, d_first, d_count, k1_list_t{},
-                                                                             g_k1_stamps);
+    static uint32_t stamp_cap = 0;
+    if (blocks > stamp_cap) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_k1_stamps);
+        (void)hipMalloc((void **)&g_k1_stamps, 16u * 8u * (size_t)blocks);
+        stamp_cap = blocks;
+    }
+    g_k1_stamp_blocks = blocks;
+    if (bulk)
+        k1_match_indexed<true, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(
+            d_S, d_s_off, N, spb, str_cap, s_aligned, sub_cap, T, d_first, d_count, k1_list_t{}, g_k1_stamps);
+    else
+        k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(
+            d_S, d_s_off, N, spb, str_cap, s_aligned, sub_cap, T, d_first, d_count, k1_list_t{}, g_k1_stamps);
 #else
     /* eight lanes per survivor while a block's waves see few survivors at a
      * time; a lane per survivor once every pass fills its wave (measured: the
@@ -1004,16 +1196,16 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     const k1_list_t L{d_list_off, d_list_idx, ctx->d_dup_start, ctx->d_dup_idx};
     if (d_list_off && bulk)
         k1_match_indexed<true, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                               s_aligned, T, nullptr, nullptr, L);
+                                                                               s_aligned, sub_cap, T, nullptr, nullptr, L);
     else if (d_list_off)
         k1_match_indexed<false, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                                s_aligned, T, nullptr, nullptr, L);
+                                                                                s_aligned, sub_cap, T, nullptr, nullptr, L);
     else if (bulk)
         k1_match_indexed<true, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                                s_aligned, T, d_first, d_count, L);
+                                                                                s_aligned, sub_cap, T, d_first, d_count, L);
     else
         k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                                 s_aligned, T, d_first, d_count, L);
+                                                                                 s_aligned, sub_cap, T, d_first, d_count, L);
 #endif
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;

@@ -119,6 +119,31 @@ typedef struct {
     uint32_t pad[4];
 } mcx_slot_t;
 
+/* Large groups (more than MCX_SUB_MIN patterns under one key: the prefix says
+ * little, e.g. every "of:N*T*C..." line) carry a second index.  pad[0] of
+ * the group's slot = group number + 1 (0: none), pad[1] = number of patterns
+ * at the head of the group that have no anchor gram.  Every other pattern of
+ * the group names one four-byte window of its literals that any string it
+ * matches must hold (its anchor gram); the group is ordered by anchor gram, and
+ * (group, gram) -> run of patterns is a second open-addressing table with tag
+ * bytes of its own.  A caller that ignores it scans the whole group. */
+#define MCX_SUB_MIN 128u
+typedef struct {
+    uint32_t gram;  /* the four bytes, first byte lowest */
+    uint32_t gid;   /* group number */
+    uint32_t start; /* first pattern of the run, in index order */
+    uint32_t count; /* 0: empty entry */
+} mcx_sub_t;
+
+MCX_HD uint32_t mcx_sub_hash(uint32_t gram, uint32_t gid)
+{
+    uint32_t a = (gram ^ (gid * 0x9E3779B1u)) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    a *= 0x7FEB352Du;
+    a ^= a >> 16;
+    return a;
+}
+
 /* One byte per index slot, read before the 64-byte entry where misses are the
  * rule: 0 marks an empty slot, anything else is this function of the key's hash. */
 MCX_HD uint32_t mcx_key_tag(uint32_t hash)

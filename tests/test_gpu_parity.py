@@ -176,6 +176,32 @@ def test_k1_single_key_length_tables(gpu_ctx, oracle_mod, N):
     assert (count > 0).any() or N == 1
 
 
+@pytest.mark.parametrize("sub_min,norm", [(3, False), (40, False), (3, True)])
+def test_k1_second_index_of_large_groups(gpu_ctx, oracle_mod, monkeypatch, sub_min, norm):
+    """Large batches look large pattern groups up by the grams of the string.  With the
+    size from which a group counts as large set low, the synthetic table has hundreds of
+    such groups and a block meets more (string, group) pairs and runs than it has room
+    for, so the whole-group way out is taken as well; first_idx, count and the match
+    lists must not notice any of it."""
+    monkeypatch.setenv("MCX_SUB_MIN", str(sub_min))
+    P, N = 30000, 70000
+    A, a_off, a_mod = synth.alias_table(9, P)
+    S, s_off = synth.modalias_strings(9, P, N)
+    flags = 1 if norm else 0
+    gpu_ctx.alias_table_load(A, a_off, a_mod, flags)
+    first, count = gpu_ctx.alias_match(S, s_off)
+    monkeypatch.delenv("MCX_SUB_MIN")
+    t_first, t_count = oracle_mod.alias_match(A, a_off, S, s_off, normalize_dash=norm, use_twin=True)
+    assert np.array_equal(first, t_first) and np.array_equal(count, t_count)
+    o_first, o_count = oracle_mod.alias_match(A, a_off, S, s_off, normalize_dash=norm, i0=0, i1=60)
+    assert np.array_equal(first[:60], o_first) and np.array_equal(count[:60], o_count)
+    off, idx = gpu_ctx.alias_match_list(S, s_off)
+    assert np.array_equal(np.diff(off.astype(np.int64)), count)
+    assert np.array_equal(idx[off[:-1][count > 0]], first[count > 0])
+    o_off, o_idx = oracle_mod.alias_match_list(A, a_off, S[: s_off[60]], s_off[:61], normalize_dash=norm)
+    assert np.array_equal(idx[: off[60]], o_idx)
+
+
 def test_k1_random_metachar_tables(gpu_ctx, oracle_mod):
     """random patterns heavy in metacharacters (those the compiler accepts)"""
     import random
