@@ -578,6 +578,8 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         size_t g1 = g0 + 1;
         while (g1 < n_idx && keys[order[g1]] == keys[order[g0]])
             ++g1;
+        if (g1 - g0 > out.max_group)
+            out.max_group = (uint32_t)(g1 - g0);
         if (g1 - g0 > sub_min) {
             const size_t keylen = keys[order[g0]].size();
             std::vector<std::vector<uint32_t>> cand(g1 - g0);

@@ -39,6 +39,7 @@ struct mcx_compiled_table {
     std::vector<mcx_sub_t> sub;      /* (large group, anchor gram) -> run of patterns, 2^k entries */
     std::vector<uint8_t> sub_tags;   /* per entry of sub: 0 = empty, else mcx_key_tag of its hash */
     uint32_t n_sub_groups = 0;       /* groups that have a second index        */
+    uint32_t max_group = 0;          /* patterns in the largest group          */
     std::vector<uint32_t> lens;      /* distinct key lengths, ascending       */
     std::vector<uint32_t> sets;      /* distinct bracket sets, 8 words each   */
     std::map<std::array<uint32_t, 8>, uint32_t> set_ids; /* set bits -> number */

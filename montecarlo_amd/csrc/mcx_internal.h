@@ -40,7 +40,7 @@ struct mcx_ctx {
     uint8_t *d_tags = nullptr;       /* one tag byte per index slot            */
     mcx_sub_t *d_sub = nullptr;      /* second index of the large groups       */
     uint8_t *d_sub_tags = nullptr;
-    uint32_t sub_mask = 0, n_sub_groups = 0;
+    uint32_t sub_mask = 0, n_sub_groups = 0, max_group = 0;
     uint32_t slot_mask = 0;
     uint32_t nlens = 0;
     uint32_t *d_sets = nullptr;

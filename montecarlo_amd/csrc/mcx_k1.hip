@@ -1071,6 +1071,7 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
     ctx->slot_mask = (uint32_t)t.slots.size() - 1u;
     ctx->sub_mask = (uint32_t)t.sub.size() - 1u;
     ctx->n_sub_groups = t.n_sub_groups;
+    ctx->max_group = t.max_group;
     ctx->nlens = (uint32_t)t.lens.size();
     ctx->norm_dash = (flags & MCX_TABLE_NORMALIZE_DASH) != 0;
     ctx->table_bytes = 4 * (uint64_t)(t.slot.size() + t.ext.size() + t.sig.size() + t.sets.size() + t.lens.size() +
@@ -1111,6 +1112,22 @@ extern "C" int mcx_debug_k1_stamps(unsigned long long *out, uint32_t max_blocks)
 /* list_off == nullptr: first_idx / count.  Otherwise the list variant: every
  * match is written into d_list_idx at the place list_off (the exclusive sums
  * of a counting pass over the same strings) gives its string. */
+/* Which of the two variants of the kernel a batch gets.  Eight lanes per survivor
+ * while a block's waves see few survivors at a time, a lane per survivor once every
+ * pass fills its wave: measured against 3 x 10^4 patterns the two meet at about
+ * 16 000 strings.  Only the large-batch variant uses the second index of the large
+ * groups, and against a table with a very large group (every "of:" line of a table of
+ * 3 x 10^6 patterns shares one prefix) that decides it whatever the batch: 1000 strings
+ * take 25 us with it and 78 us without (equal at 3 x 10^5 patterns, largest group 11 800).
+ * Test seam: MCX_BULK_MIN in the environment replaces the batch size. */
+static bool k1_use_bulk(const mcx_ctx *ctx, uint32_t N)
+{
+    const char *env = getenv("MCX_BULK_MIN");
+    if (env && *env)
+        return N >= (uint32_t)strtoul(env, nullptr, 10);
+    return N >= 16384u || (ctx->n_sub_groups != 0u && ctx->max_group >= 8192u);
+}
+
 static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
                               uint32_t *d_first, uint32_t *d_count, const uint32_t *d_list_off = nullptr,
                               uint32_t *d_list_idx = nullptr)
@@ -1149,7 +1166,7 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
      * may be added to this without looking at the occupancy.  A table with many key lengths
      * has larger hit arrays; the staging buffer then gives way (down to 128 bytes per string)
      * so that the fifth block still fits. */
-    const bool bulk = N >= 65536u;
+    const bool bulk = k1_use_bulk(ctx, N);
     uint32_t sub_cap = 0; /* entries for the runs found through the second index (large batches) */
     auto lds_bytes = [&](uint32_t cap, uint32_t subs) {
         return 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)cap / 4 + 5 + 3 * (size_t)spb * T.nlens + 2 * (size_t)subs + 1);
@@ -1190,9 +1207,6 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(
             d_S, d_s_off, N, spb, str_cap, s_aligned, sub_cap, T, d_first, d_count, k1_list_t{}, g_k1_stamps);
 #else
-    /* eight lanes per survivor while a block's waves see few survivors at a
-     * time; a lane per survivor once every pass fills its wave (measured: the
-     * two meet at about 10^5 strings against 3 x 10^4 patterns) */
     const k1_list_t L{d_list_off, d_list_idx, ctx->d_dup_start, ctx->d_dup_idx};
     if (d_list_off && bulk)
         k1_match_indexed<true, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,

@@ -90,6 +90,14 @@ while time.time() < t_end:
             sys.exit(0)
         rnd.sample(range(N), min(N, 3 if P > 20000 else 12))
         continue
+    # the two test seams of the library, drawn per case: the group size from which a group
+    # gets a second index, and the batch size from which the large-batch kernel runs
+    knobs = {"MCX_SUB_MIN": rnd.choice([None, None, "3", "20"]), "MCX_BULK_MIN": rnd.choice([None, None, "1", "100000000"])}
+    for k, v in knobs.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     try:
         ctx.alias_table_load(A, a_off, np.zeros(P, dtype=np.uint32), flags=1 if norm else 0)
     except Exception as e:                     # noqa: BLE001 - a table kmod's rule refuses: skip
@@ -102,7 +110,8 @@ while time.time() < t_end:
     Ss, ss_off = pack_strings([S[s_off[i]:s_off[i + 1]].tobytes() for i in pick])
     g_first, g_count = oracle.alias_match(A, a_off, Ss, ss_off, normalize_dash=norm)
     ok = ok and np.array_equal(first[pick], g_first) and np.array_equal(count[pick], g_count)
-    print(f"case {case}: {kind} P={P} N={N} norm={int(norm)} matches={int(count.sum())} {'ok' if ok else 'MISMATCH'}",
+    print(f"case {case}: {kind} P={P} N={N} norm={int(norm)} sub_min={knobs['MCX_SUB_MIN']} bulk_min={knobs['MCX_BULK_MIN']} "
+          f"matches={int(count.sum())} {'ok' if ok else 'MISMATCH'}",
           flush=True)
     if not ok:
         bad = np.nonzero((first != t_first) | (count != t_count))[0][:5]

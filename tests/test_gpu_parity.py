@@ -202,6 +202,30 @@ def test_k1_second_index_of_large_groups(gpu_ctx, oracle_mod, monkeypatch, sub_m
     assert np.array_equal(idx[: off[60]], o_idx)
 
 
+@pytest.mark.parametrize("N", [1, 100, 2049, 5000, 12000])
+def test_k1_large_batch_kernel_on_small_batches(gpu_ctx, oracle_mod, monkeypatch, N):
+    """A table with a very large group sends every batch to the large-batch kernel; here
+    the batch-size seam does, so that it runs with one to six strings per block."""
+    monkeypatch.setenv("MCX_BULK_MIN", "1")
+    monkeypatch.setenv("MCX_SUB_MIN", "5")
+    P = 20000
+    A, a_off, a_mod = synth.alias_table(11, P)
+    S, s_off = synth.modalias_strings(11, P, N)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    first, count = gpu_ctx.alias_match(S, s_off)
+    off, idx = gpu_ctx.alias_match_list(S, s_off)
+    monkeypatch.delenv("MCX_BULK_MIN")
+    t_first, t_count = oracle_mod.alias_match(A, a_off, S, s_off, use_twin=True)
+    assert np.array_equal(first, t_first) and np.array_equal(count, t_count)
+    assert np.array_equal(np.diff(off.astype(np.int64)), count)
+    n = min(N, 40)
+    o_first, o_count = oracle_mod.alias_match(A, a_off, S, s_off, i0=0, i1=n)
+    assert np.array_equal(first[:n], o_first) and np.array_equal(count[:n], o_count)
+    # the other kernel, same answers
+    f2, c2 = gpu_ctx.alias_match(S, s_off)
+    assert np.array_equal(first, f2) and np.array_equal(count, c2)
+
+
 def test_k1_random_metachar_tables(gpu_ctx, oracle_mod):
     """random patterns heavy in metacharacters (those the compiler accepts)"""
     import random
