@@ -45,6 +45,24 @@ def _worker(rank, world, port, out_dir):
     first, count = oracle.alias_match(A, a_off, Sr, sr_off)
     np.save(os.path.join(out_dir, f"str_first_{rank}.npy"), first)
     np.save(os.path.join(out_dir, f"str_count_{rank}.npy"), count)
+    # match lists of the pattern-sharded mode, merged by all-gather
+    j0, j1 = shard.shard_range(P, rank, world)
+    A, a_off, a_mod = synth.alias_table(SEED, P, j0, j1)
+    off, idx = oracle.alias_match_list(A, a_off, S, s_off)
+    g_off, g_idx = shard.gather_match_lists(shard.as_i32(off), shard.as_i32(idx), j0)
+    np.save(os.path.join(out_dir, f"list_off_{rank}.npy"), g_off.numpy())
+    np.save(os.path.join(out_dir, f"list_idx_{rank}.npy"), g_idx.numpy())
+    # per-host lists of a host-sharded fleet pass: ragged CSRs, rank 1 may own no host
+    H = 7
+    h0, h1 = shard.shard_range(H, rank, world)
+    sizes = [(3 * h) % 5 for h in range(H)]
+    ids = [np.arange(sizes[h], dtype=np.uint32) + 100 * h for h in range(h0, h1)]
+    r_off = np.zeros(h1 - h0 + 1, dtype=np.uint32)
+    r_off[1:] = np.cumsum([len(x) for x in ids])
+    r_ids = np.concatenate(ids) if ids else np.zeros(0, dtype=np.uint32)
+    f_off, f_ids = shard.gather_host_lists(shard.as_i32(r_off), shard.as_i32(r_ids))
+    np.save(os.path.join(out_dir, f"fleet_off_{rank}.npy"), f_off.numpy())
+    np.save(os.path.join(out_dir, f"fleet_ids_{rank}.npy"), f_ids.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,8 +89,8 @@ def test_first_index_order_mapping():
     assert shard.as_u32(m).tolist() == [3, 105, 0xFFFFFFFF, 2]
 
 
-def test_two_rank_gloo_combine(tmp_path, oracle_mod):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_combine(tmp_path, oracle_mod, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     A, a_off, a_mod = synth.alias_table(SEED, P)
     S, s_off = synth.modalias_strings(SEED, P, N)
@@ -84,3 +102,11 @@ def test_two_rank_gloo_combine(tmp_path, oracle_mod):
     sf = np.concatenate([np.load(tmp_path / f"str_first_{r}.npy") for r in range(world)])
     sc = np.concatenate([np.load(tmp_path / f"str_count_{r}.npy") for r in range(world)])
     assert np.array_equal(sf, first) and np.array_equal(sc, count)
+    o_off, o_idx = oracle_mod.alias_match_list(A, a_off, S, s_off)
+    sizes = [(3 * h) % 5 for h in range(7)]
+    want_ids = np.concatenate([np.arange(sizes[h]) + 100 * h for h in range(7)])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"list_off_{r}.npy"), o_off.astype(np.int64))
+        assert np.array_equal(np.load(tmp_path / f"list_idx_{r}.npy"), o_idx.astype(np.int64))
+        assert np.array_equal(np.load(tmp_path / f"fleet_off_{r}.npy"), np.concatenate([[0], np.cumsum(sizes)]))
+        assert np.array_equal(np.load(tmp_path / f"fleet_ids_{r}.npy"), want_ids)
