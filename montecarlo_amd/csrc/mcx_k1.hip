@@ -318,6 +318,67 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
      * string then sit in front of it in the buffer */
     const uint32_t shift = (use_lds && s_aligned) ? (gbase & 3u) : 0u;
 
+    /* Small batches: the probe of the index does not wait for the tile to be staged.  Its
+     * lanes (the last wave first) read the first bytes of their string straight from the
+     * arena and walk the index while the other waves stage and build the gram sets; what
+     * they found is recorded after the barrier.  (Not with kmod's dash rule, whose strings
+     * are rewritten in LDS first, and not for an arena that cannot be read by words.) */
+    const bool early = !BULK && T.norm_dash == 0u && s_aligned != 0u;
+    uint32_t e_start = 0, e_cnt = 0, e_slot = 0;
+    if constexpr (!BULK) {
+        const uint32_t pr = (K1_THREADS - 1u) - tid;
+        if (early && pr < nstr * T.nlens) {
+            const uint32_t slot = T.nlens == 1u ? pr : __umulhi(pr, T.nlens_magic);
+            const uint32_t KL = T.lens[pr - slot * T.nlens];
+            const uint32_t so = s_off[t0 + slot], len = s_off[t0 + slot + 1u] - so;
+            if (KL <= len) {
+                const uint32_t sh = 8u * (so & 3u), a0 = so & ~3u;
+                uint32_t raw[MCX_KEY_MAX / 4 + 1];
+#pragma unroll
+                for (uint32_t k = 0; k <= MCX_KEY_MAX / 4; ++k) {
+                    const uint32_t b0 = a0 + 4u * k;
+                    uint32_t v = 0;
+                    if (b0 < so + KL) {
+                        if (b0 + 4u <= arena_end) {
+                            v = *(const uint32_t *)(S + b0);
+                        } else {
+                            for (uint32_t j = 0; j < 4u; ++j)
+                                if (b0 + j < arena_end)
+                                    v |= (uint32_t)S[b0 + j] << (8u * j);
+                        }
+                    }
+                    raw[k] = v;
+                }
+                uint32_t kw[MCX_KEY_MAX / 4];
+#pragma unroll
+                for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k) {
+                    uint32_t v = (uint32_t)((((uint64_t)raw[k + 1] << 32) | raw[k]) >> sh);
+                    if (4u * k >= KL)
+                        v = 0;
+                    else if ((KL >> 2) == k && (KL & 3u))
+                        v &= 0xFFFFFFFFu >> (8u * (4u - (KL & 3u)));
+                    kw[k] = v;
+                }
+                const uint32_t a = mcx_key_hash(kw, KL);
+                for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
+                    const mcx_slot_t sl = T.slots[at];
+                    if (sl.count == 0u)
+                        break;
+                    bool same = sl.hash == a && sl.len == KL;
+#pragma unroll
+                    for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                        same = same && sl.key[k] == kw[k];
+                    if (same) {
+                        e_start = sl.start;
+                        e_cnt = sl.count;
+                        e_slot = slot;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+
     if (tid < T.nlens)
         key_lens[tid] = T.lens[tid];
     for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
@@ -421,7 +482,15 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pt1 = pt0, pt2 = pt0;
 #endif
     const uint32_t nprobe = nstr * T.nlens;
-    for (uint32_t pr = (K1_THREADS - 1u) - tid; pr < nprobe; pr += K1_THREADS) {
+    uint32_t pr_first = (K1_THREADS - 1u) - tid;
+    if constexpr (!BULK) {
+        if (early) {
+            if (e_cnt)
+                emit_hit(e_start, e_cnt, e_slot);
+            pr_first += K1_THREADS; /* a block with more than K1_THREADS probes: the rest the usual way */
+        }
+    }
+    for (uint32_t pr = pr_first; pr < nprobe; pr += K1_THREADS) {
         /* pr / nlens; a table with a single key length has no 32-bit reciprocal */
         const uint32_t slot = T.nlens == 1u ? pr : __umulhi(pr, T.nlens_magic), L = key_lens[pr - slot * T.nlens];
         const uint32_t len = str_len[slot];
