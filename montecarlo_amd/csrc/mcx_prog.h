@@ -461,11 +461,27 @@ MCX_HD uint64_t mcx_seg_mask_from(const Prog &p, const mcx_seg_t &g, uint32_t v,
             if ((w1 >> 8) & 1u)
                 cls = all & ~cls & ~occ[0u];
         } else {
+            /* the eight words of the set are asked for together (they live in global
+             * memory), and the table is read for up to four members at a time: a
+             * member-by-member loop is a chain of waits */
+            uint32_t sw[8];
+            MCX_UNROLL
+            for (uint32_t wi = 0; wi < 8u; ++wi)
+                sw[wi] = sets[(w0 >> 16) * 8u + wi];
+            MCX_UNROLL
             for (uint32_t wi = 0; wi < 8u; ++wi) {
-                uint32_t bits = sets[(w0 >> 16) * 8u + wi];
+                uint32_t bits = sw[wi];
                 while (bits) {
-                    cls |= occ[wi * 32u + (uint32_t)__builtin_ctz(bits)];
-                    bits &= bits - 1u;
+                    uint64_t o[4];
+                    MCX_UNROLL
+                    for (uint32_t t = 0; t < 4u; ++t) {
+                        const bool any = bits != 0u;
+                        const uint32_t b = any ? (uint32_t)__builtin_ctz(bits) : 0u;
+                        const uint64_t v = occ[wi * 32u + b];
+                        o[t] = any ? v : 0u;
+                        bits &= bits - 1u;
+                    }
+                    cls |= (o[0] | o[1]) | (o[2] | o[3]);
                 }
             }
         }
