@@ -155,7 +155,7 @@ def main():
 
     dist = None
     # rehearsal of the multi-rank path on a box with fewer GPUs than ranks: every rank on GPU 0,
-    # rendezvous and reductions over gloo on host tensors (string sharding only)
+    # rendezvous and reductions over gloo on host tensors
     rehearse = os.environ.get("MCX_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -194,7 +194,14 @@ def main():
 
     def step():
         ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, t_first.data_ptr(), t_count.data_ptr())
-        if by_pattern:
+        if by_pattern and rehearse:
+            # gloo reduces host tensors: the rehearsal takes the results through the host
+            stream.synchronize()
+            f, c = t_first.cpu(), t_count.cpu()
+            shard.combine_pattern_shards(f, c, j0)
+            t_first.copy_(f)
+            t_count.copy_(c)
+        elif by_pattern:
             with torch.cuda.stream(stream):
                 shard.combine_pattern_shards(t_first, t_count, j0)
 
