@@ -25,7 +25,7 @@
 #define K2_ROWS 256u
 #define K2_EDGES 4096u
 #define K2B_BLOCKS 1024u  /* grid of one BFS level; strides over the frontier */
-#define K2B_BATCH 8u      /* levels enqueued between two looks at the queue size */
+#define K2B_BATCH 16u     /* most levels enqueued between two looks at the queue sizes */
 #define K2B_MAX_LEVELS 4096u
 
 /* ------------------------------------------------------------------------- */
@@ -726,6 +726,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         if (ea != hipSuccess)
             ctx->n_cu_part = 0;
     }
+    ctx->bfs_depth[0] = ctx->bfs_depth[1] = 0;
     ctx->graph_loaded = true;
     return MCX_OK;
 }
@@ -825,19 +826,25 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     k2b_seed<<<(W + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
         (const uint32_t *)d_seed_bitmap, (const uint8_t *)d_in_flags, V, (uint32_t *)d_out_bitmap,
         ctx->d_queue[0], st);
-    /* levels are enqueued K2B_BATCH at a time; a level whose frontier is empty
-     * returns at once, and the queue sizes of a batch tell where the search
-     * ended.  A path visits each vertex once, so V levels always suffice. */
+    /* levels are enqueued a batch at a time; a level whose frontier is empty
+     * returns at once (1.7 us), and the queue sizes of a batch tell where the search
+     * ended; looking costs a stream synchronisation (25 us).  Searches over one graph
+     * tend to be equally deep, so a batch is as long as the last search in this
+     * direction was, plus two: a shallow search does not pay for a dozen empty levels
+     * and a deep one looks once.  A path visits each vertex once, so V levels always
+     * suffice. */
+    const uint32_t hint = ctx->bfs_depth[direction];
+    const uint32_t batch = hint ? (hint + 2u < 4u ? 4u : (hint + 2u > K2B_BATCH ? K2B_BATCH : hint + 2u)) : 8u;
     uint32_t lv = 0;
     uint32_t *sizes = ctx->h_pinned;                                  /* 2 * K2B_BATCH words */
     unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 2 * K2B_BATCH);
     bool done = false;
     while (!done) {
-        if (lv + K2B_BATCH > K2B_MAX_LEVELS) {
+        if (lv + batch > K2B_MAX_LEVELS) {
             ctx->err = "closure deeper than 4096 levels";
             return MCX_E_TOO_LARGE;
         }
-        for (uint32_t b = 0; b < K2B_BATCH; ++b) {
+        for (uint32_t b = 0; b < batch; ++b) {
             const uint32_t level = lv + b;
             k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags,
                                                                   ctx->d_queue[level & 1u],
@@ -845,10 +852,10 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                                                                   ctx->d_queue[(level + 1u) & 1u], st, level);
         }
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(sizes, &st.cnt[2u * lv], 8 * K2B_BATCH, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(sizes, &st.cnt[2u * lv], 8 * batch, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(h_edges, st.edges, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t b = 0; b < K2B_BATCH; ++b) {
+        for (uint32_t b = 0; b < batch; ++b) {
             if (sizes[2u * b] == 0u && sizes[2u * b + 1u] == 0u) {
                 done = true;
                 break;
@@ -860,6 +867,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
         *edges_scanned = *h_edges;
     if (levels)
         *levels = lv;
+    ctx->bfs_depth[direction] = lv ? lv : 1u;
     return MCX_OK;
 }
 
