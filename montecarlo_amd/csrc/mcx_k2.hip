@@ -796,6 +796,19 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uin
     return rc;
 }
 
+/* the queue sizes of a batch of levels and the edge count, written straight into
+ * pinned host memory: one small launch instead of two device-to-host copies */
+__global__ void k2b_publish(const uint32_t *__restrict__ cnt, uint32_t nwords,
+                            const unsigned long long *__restrict__ edges, uint32_t *__restrict__ h_sizes,
+                            unsigned long long *__restrict__ h_edges)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < nwords)
+        h_sizes[i] = cnt[i];
+    if (i == 0)
+        *h_edges = *edges;
+}
+
 int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed_bitmap, void *d_out_bitmap,
                         int direction, uint64_t *edges_scanned, uint32_t *levels)
 {
@@ -838,6 +851,9 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     uint32_t lv = 0;
     uint32_t *sizes = ctx->h_pinned;                                  /* 2 * K2B_BATCH words */
     unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 2 * K2B_BATCH);
+    uint32_t *d_sizes = nullptr; /* the same pinned memory as the device addresses it */
+    HIPCHK(ctx, hipHostGetDevicePointer((void **)&d_sizes, sizes, 0));
+    unsigned long long *d_edges = (unsigned long long *)(d_sizes + 2 * K2B_BATCH);
     bool done = false;
     while (!done) {
         if (lv + batch > K2B_MAX_LEVELS) {
@@ -852,8 +868,8 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                                                                   ctx->d_queue[(level + 1u) & 1u], st, level);
         }
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(sizes, &st.cnt[2u * lv], 8 * batch, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(h_edges, st.edges, 8, hipMemcpyDeviceToHost, ctx->stream));
+        k2b_publish<<<1, 64, 0, ctx->stream>>>(&st.cnt[2u * lv], 2u * batch, st.edges, d_sizes, d_edges);
+        HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (uint32_t b = 0; b < batch; ++b) {
             if (sizes[2u * b] == 0u && sizes[2u * b + 1u] == 0u) {
