@@ -135,6 +135,8 @@ void mcx_ctx_destroy(mcx_ctx *ctx)
     mcx_free_graph(ctx);
     (void)hipFree(ctx->d_fleet);
     (void)hipFree(ctx->d_io);
+    if (ctx->h_io)
+        (void)hipHostFree(ctx->h_io);
     if (ctx->h_pinned)
         (void)hipHostFree(ctx->h_pinned);
     if (ctx->ev0)

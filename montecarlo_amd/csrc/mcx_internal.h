@@ -76,6 +76,8 @@ struct mcx_ctx {
     /* staging of the host-buffer alias match, grown on demand */
     void *d_io = nullptr;
     size_t io_bytes = 0;
+    void *h_io = nullptr;          /* pinned mirror of d_io for small host-buffer calls */
+    size_t h_io_bytes = 0;
 
     /* scratch of the fleet pipeline, grown on demand, freed with the context */
     void *d_fleet = nullptr;

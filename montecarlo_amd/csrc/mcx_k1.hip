@@ -25,6 +25,7 @@
 #define K1_MAX_PATTERNS (1u << 26) /* survivor entries and group counts keep a pattern number in 26 bits */
 #define K1_CU_LDS_BYTES 163840u /* LDS of one gfx950 CU */
 #define K1_LDS_GRANULE 1280u    /* ... allocated to blocks in pieces of this size */
+#define MCX_ZERO_COPY_MAX ((size_t)256 << 10) /* host-buffer calls up to this size: the kernel works on pinned host memory */
 #define K1_QUARTER 64u
 #define K1_LANEMAP 512u  /* screening lanes the small groups of one block can take */
 #define K1_BIGLIST 32u   /* (string, large group) pairs of one block that go through the second index */
@@ -1331,6 +1332,36 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
     const size_t o_off = (sbytes + 255) & ~(size_t)255, o_first = o_off + ((4 * ((size_t)N + 1) + 255) & ~(size_t)255);
     const size_t o_count = o_first + ((4 * (size_t)N + 255) & ~(size_t)255);
     const size_t need = o_count + 4 * (size_t)N;
+    /* Small calls are all transfer set-up: four copies between pageable memory and the
+     * device cost several times the kernel.  They use no copies at all: strings and
+     * offsets are put into pinned host memory, the kernel reads them there (a few reads
+     * over the bus per block) and writes the results there. */
+    if (need <= MCX_ZERO_COPY_MAX) {
+        if (ctx->h_io_bytes < need) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipHostFree(ctx->h_io);
+            ctx->h_io = nullptr;
+            ctx->h_io_bytes = 0;
+            if (hipHostMalloc(&ctx->h_io, MCX_ZERO_COPY_MAX, hipHostMallocDefault) != hipSuccess) {
+                ctx->err = "hipHostMalloc of the pinned staging area failed";
+                return MCX_E_NOMEM;
+            }
+            ctx->h_io_bytes = MCX_ZERO_COPY_MAX;
+        }
+        uint8_t *hb = (uint8_t *)ctx->h_io, *db = nullptr;
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&db, hb, 0));
+        if (sbytes)
+            memcpy(hb, S, sbytes);
+        memcpy(hb + o_off, s_off, 4 * ((size_t)N + 1));
+        int rc0 = launch_alias_match(ctx, db, (const uint32_t *)(db + o_off), N, (uint32_t *)(db + o_first),
+                                     (uint32_t *)(db + o_count));
+        if (rc0 != MCX_OK)
+            return rc0;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(first_idx, hb + o_first, 4 * (size_t)N);
+        memcpy(count, hb + o_count, 4 * (size_t)N);
+        return MCX_OK;
+    }
     if (ctx->io_bytes < need) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->d_io);
