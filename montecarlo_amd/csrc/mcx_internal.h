@@ -124,6 +124,28 @@ static inline size_t up256(size_t x)
     return (x + 255) & ~(size_t)255;
 }
 
+/* The context's device staging area for host-buffer calls, grown on demand (one
+ * allocation kept between calls: a hipMalloc / hipFree pair per call costs more
+ * than the small kernels it would serve).  Calls on one context are serial. */
+static inline int mcx_io_reserve(mcx_ctx *ctx, size_t need, uint8_t **base)
+{
+    if (ctx->io_bytes < need) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return MCX_E_HIP;
+        (void)hipFree(ctx->d_io);
+        ctx->d_io = nullptr;
+        ctx->io_bytes = 0;
+        const size_t want = need + need / 2;
+        if (hipMalloc(&ctx->d_io, want) != hipSuccess) {
+            ctx->err = "hipMalloc of " + std::to_string(want) + " bytes of staging failed";
+            return MCX_E_NOMEM;
+        }
+        ctx->io_bytes = want;
+    }
+    *base = (uint8_t *)ctx->d_io;
+    return MCX_OK;
+}
+
 template <class T>
 static int mcx_dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 {

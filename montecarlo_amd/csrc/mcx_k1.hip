@@ -1362,19 +1362,12 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
         memcpy(count, hb + o_count, 4 * (size_t)N);
         return MCX_OK;
     }
-    if (ctx->io_bytes < need) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_io);
-        ctx->d_io = nullptr;
-        ctx->io_bytes = 0;
-        const size_t want = need + need / 2;
-        if (hipMalloc(&ctx->d_io, want) != hipSuccess) {
-            ctx->err = "hipMalloc of " + std::to_string(want) + " bytes of staging failed";
-            return MCX_E_NOMEM;
-        }
-        ctx->io_bytes = want;
+    uint8_t *base = nullptr;
+    {
+        const int rc_io = mcx_io_reserve(ctx, need, &base);
+        if (rc_io != MCX_OK)
+            return rc_io;
     }
-    uint8_t *base = (uint8_t *)ctx->d_io;
     uint32_t *d_off = (uint32_t *)(base + o_off), *d_first = (uint32_t *)(base + o_first);
     uint32_t *d_count = (uint32_t *)(base + o_count);
     if (sbytes)

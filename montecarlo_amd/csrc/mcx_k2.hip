@@ -771,15 +771,15 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uin
         return MCX_OK;
     if (mcx_set_device(ctx))
         return MCX_E_HIP;
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    uint32_t *d_ref = nullptr;
-    int rc = MCX_OK;
-    if (hipMalloc((void **)&d_in, V) != hipSuccess || hipMalloc((void **)&d_out, V) != hipSuccess ||
-        (refcnt && hipMalloc((void **)&d_ref, 4 * (size_t)V) != hipSuccess)) {
-        ctx->err = "hipMalloc failed";
-        rc = MCX_E_NOMEM;
-    }
-    if (rc == MCX_OK && hipMemcpyAsync(d_in, in_flags, V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    /* flags in, flags out, reference counts: three pieces of the context's staging area */
+    const size_t piece = ((size_t)V + 255) & ~(size_t)255;
+    uint8_t *base = nullptr;
+    int rc = mcx_io_reserve(ctx, 2 * piece + 4 * (size_t)V, &base);
+    if (rc != MCX_OK)
+        return rc;
+    uint8_t *d_in = base, *d_out = base + piece;
+    uint32_t *d_ref = refcnt ? (uint32_t *)(base + 2 * piece) : nullptr;
+    if (hipMemcpyAsync(d_in, in_flags, V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         rc = MCX_E_HIP;
     if (rc == MCX_OK)
         rc = mcx_dep_flags_dev(ctx, d_in, d_out, d_ref);
@@ -790,9 +790,6 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uin
         rc = MCX_E_HIP;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MCX_OK)
         rc = MCX_E_HIP;
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    (void)hipFree(d_ref);
     return rc;
 }
 
@@ -899,17 +896,17 @@ int mcx_dep_closure(mcx_ctx *ctx, const uint8_t *in_flags, const uint32_t *seed_
         return MCX_OK;
     if (mcx_set_device(ctx))
         return MCX_E_HIP;
-    size_t wb = 4 * (size_t)((V + 31) / 32);
-    uint8_t *d_in = nullptr;
-    uint32_t *d_seed = nullptr, *d_out = nullptr;
-    int rc = MCX_OK;
-    if (hipMalloc((void **)&d_in, V) != hipSuccess || hipMalloc((void **)&d_seed, wb) != hipSuccess ||
-        hipMalloc((void **)&d_out, wb) != hipSuccess) {
-        ctx->err = "hipMalloc failed";
-        rc = MCX_E_NOMEM;
-    }
-    if (rc == MCX_OK && (hipMemcpyAsync(d_in, in_flags, V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                         hipMemcpyAsync(d_seed, seed_bitmap, wb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
+    /* flags, seed bitmap, result bitmap: three pieces of the context's staging area */
+    const size_t wb = 4 * (size_t)((V + 31) / 32);
+    const size_t p_in = ((size_t)V + 255) & ~(size_t)255, p_bm = (wb + 255) & ~(size_t)255;
+    uint8_t *base = nullptr;
+    int rc = mcx_io_reserve(ctx, p_in + 2 * p_bm, &base);
+    if (rc != MCX_OK)
+        return rc;
+    uint8_t *d_in = base;
+    uint32_t *d_seed = (uint32_t *)(base + p_in), *d_out = (uint32_t *)(base + p_in + p_bm);
+    if (hipMemcpyAsync(d_in, in_flags, V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_seed, seed_bitmap, wb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         rc = MCX_E_HIP;
     if (rc == MCX_OK)
         rc = mcx_dep_closure_dev(ctx, d_in, d_seed, d_out, direction, edges_scanned, levels);
@@ -917,9 +914,6 @@ int mcx_dep_closure(mcx_ctx *ctx, const uint8_t *in_flags, const uint32_t *seed_
         rc = MCX_E_HIP;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MCX_OK)
         rc = MCX_E_HIP;
-    (void)hipFree(d_in);
-    (void)hipFree(d_seed);
-    (void)hipFree(d_out);
     return rc;
 }
 
