@@ -226,6 +226,25 @@ def test_k1_large_batch_kernel_on_small_batches(gpu_ctx, oracle_mod, monkeypatch
     assert np.array_equal(first, f2) and np.array_equal(count, c2)
 
 
+@pytest.mark.parametrize("N", [1, 3700, 3850, 3950, 4100, 9000])
+def test_k1_host_buffer_call_sizes(gpu_ctx, oracle_mod, N):
+    """The host-buffer call runs the kernel on pinned host memory up to 256 KB of strings,
+    offsets and results (about 3900 of these strings) and copies through a device staging
+    area above; sizes on both sides of the switch, alternating, give the same answers."""
+    P = 5000
+    A, a_off, a_mod = synth.alias_table(13, P)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    S, s_off = synth.modalias_strings(13, P, N)
+    t_first, t_count = oracle_mod.alias_match(A, a_off, S, s_off, use_twin=True)
+    for _ in range(2):
+        first, count = gpu_ctx.alias_match(S, s_off)
+        assert np.array_equal(first, t_first) and np.array_equal(count, t_count)
+        S1, s1 = synth.modalias_strings(14, P, 5)
+        f1, c1 = gpu_ctx.alias_match(S1, s1)
+        o1, oc1 = oracle_mod.alias_match(A, a_off, S1, s1)
+        assert np.array_equal(f1, o1) and np.array_equal(c1, oc1)
+
+
 def test_k1_random_metachar_tables(gpu_ctx, oracle_mod):
     """random patterns heavy in metacharacters (those the compiler accepts)"""
     import random
