@@ -110,6 +110,19 @@ while time.time() < t_end:
     Ss, ss_off = pack_strings([S[s_off[i]:s_off[i + 1]].tobytes() for i in pick])
     g_first, g_count = oracle.alias_match(A, a_off, Ss, ss_off, normalize_dash=norm)
     ok = ok and np.array_equal(first[pick], g_first) and np.array_equal(count[pick], g_count)
+    if ok and rnd.random() < 0.4 and int(count.sum()) < 5_000_000:
+        # the list variant of the kernel: sizes = counts, heads = first matches, and the picked
+        # strings' whole lists as glibc orders them
+        K = rnd.choice([0, 0, 1, 3])
+        off, idx = ctx.alias_match_list(S, s_off, K=K)
+        want = count if K == 0 else np.minimum(count, K)
+        ok = np.array_equal(np.diff(off.astype(np.int64)), want)
+        has = want > 0
+        ok = ok and np.array_equal(idx[off[:-1][has]], first[has])
+        o_off, o_idx = oracle.alias_match_list(A, a_off, Ss, ss_off, K=K, normalize_dash=norm)
+        got = np.concatenate([idx[off[i]:off[i + 1]] for i in pick]) if pick else np.zeros(0, np.uint32)
+        ok = ok and np.array_equal(got, o_idx)
+        kind += f"+list(K={K})"
     print(f"case {case}: {kind} P={P} N={N} norm={int(norm)} sub_min={knobs['MCX_SUB_MIN']} bulk_min={knobs['MCX_BULK_MIN']} "
           f"matches={int(count.sum())} {'ok' if ok else 'MISMATCH'}",
           flush=True)
