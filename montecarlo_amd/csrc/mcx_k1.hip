@@ -25,7 +25,7 @@
 #define K1_MAX_PATTERNS (1u << 26) /* survivor entries and group counts keep a pattern number in 26 bits */
 #define K1_CU_LDS_BYTES 163840u /* LDS of one gfx950 CU */
 #define K1_LDS_GRANULE 1280u    /* ... allocated to blocks in pieces of this size */
-#define MCX_ZERO_COPY_MAX ((size_t)256 << 10) /* host-buffer calls up to this size: the kernel works on pinned host memory */
+#define MCX_ZERO_COPY_MAX ((size_t)2048 << 10) /* host-buffer calls up to this size: the kernel works on pinned host memory */
 #define K1_QUARTER 64u
 #define K1_LANEMAP 512u  /* screening lanes the small groups of one block can take */
 #define K1_BIGLIST 32u   /* (string, large group) pairs of one block that go through the second index */

@@ -10,7 +10,7 @@ from montecarlo_amd import Context, synth  # noqa: E402
 A, a_off, a_mod = synth.alias_table(2, 30000)
 ctx = Context(0)
 ctx.alias_table_load(A, a_off, a_mod)
-for N in (1, 100, 1000, 3000, 10000):
+for N in (1, 100, 1000, 3000, 10000, 25000, 60000):
     S, s_off = synth.modalias_strings(2, 30000, N)
     for _ in range(50):
         ctx.alias_match(S, s_off)

@@ -226,10 +226,10 @@ def test_k1_large_batch_kernel_on_small_batches(gpu_ctx, oracle_mod, monkeypatch
     assert np.array_equal(first, f2) and np.array_equal(count, c2)
 
 
-@pytest.mark.parametrize("N", [1, 3700, 3850, 3950, 4100, 9000])
+@pytest.mark.parametrize("N", [1, 3900, 30500, 31500, 32500, 40000])
 def test_k1_host_buffer_call_sizes(gpu_ctx, oracle_mod, N):
-    """The host-buffer call runs the kernel on pinned host memory up to 256 KB of strings,
-    offsets and results (about 3900 of these strings) and copies through a device staging
+    """The host-buffer call runs the kernel on pinned host memory up to 2 MB of strings,
+    offsets and results (about 31 000 of these strings) and copies through a device staging
     area above; sizes on both sides of the switch, alternating, give the same answers."""
     P = 5000
     A, a_off, a_mod = synth.alias_table(13, P)
