@@ -72,6 +72,19 @@ def measured_traffic(N, P):
     return None
 
 
+def measured_traffic_k2(algorithmic_bytes):
+    """HBM bytes per dependency-flag call (both kernels) from the PMC passes on file in
+    profiles/k2_traffic.json; None unless they were taken on this same graph."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "k2_traffic.json")) as f:
+            rec = json.load(f)
+        if rec.get("algorithmic_bytes_per_call") == algorithmic_bytes:
+            return rec["hbm_bytes_per_call"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline_k1(A, a_off, S, s_off, budget_s):
     """Oracle (glibc fnmatch double loop) on the same workload, all host cores
     this process may use, repeated whole passes until the budget is spent."""
@@ -328,6 +341,7 @@ def bench_k2(ctx, synth, args, with_cpu=False):
             "algorithmic_bytes": alg_flags,
             "achieved_GBs": alg_flags / (flags_ms / 1e3) / 1e9,
             "frac_of_hbm_peak": alg_flags / (flags_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": measured_traffic_k2(alg_flags),
         },
     }
     for name, direction in (("closure_holders", 0), ("closure_deps", 1)):
