@@ -1188,14 +1188,20 @@ extern "C" int mcx_debug_k1_stamps(unsigned long long *out, uint32_t max_blocks)
  * 16 000 strings.  Only the large-batch variant uses the second index of the large
  * groups, and against a table with a very large group (every "of:" line of a table of
  * 3 x 10^6 patterns shares one prefix) that decides it whatever the batch: 1000 strings
- * take 25 us with it and 78 us without (equal at 3 x 10^5 patterns, largest group 11 800).
+ * take 25 us with it and 78 us without (equal at 3 x 10^5 patterns, largest group 11 800);
+ * in between, 12 000 strings against 10^5 patterns take 45 us with it and 54 us without.
  * Test seam: MCX_BULK_MIN in the environment replaces the batch size. */
 static bool k1_use_bulk(const mcx_ctx *ctx, uint32_t N)
 {
     const char *env = getenv("MCX_BULK_MIN");
     if (env && *env)
         return N >= (uint32_t)strtoul(env, nullptr, 10);
-    return N >= 16384u || (ctx->n_sub_groups != 0u && ctx->max_group >= 8192u);
+    if (N >= 16384u)
+        return true;
+    /* the larger the largest group, the earlier the second index pays: 7000 strings against
+     * 10^5 patterns (largest group 3900), any batch from 8192 patterns in one group on */
+    return ctx->n_sub_groups != 0u &&
+           (ctx->max_group >= 8192u || (uint64_t)N * ctx->max_group >= 24000000ull);
 }
 
 static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
