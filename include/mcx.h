@@ -170,6 +170,21 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags,
 int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags,
                       void *d_refcnt);
 /*
+ * mcx_dep_flags_dev for callers that cannot allocate (code under HIP graph
+ * capture, serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same arguments and results; the LOADED bitmap
+ * the kernels gather from lives in a device array of the library's code object
+ * (MCX_NOALLOC_MAX_MODULES / 8 = 512 KiB on every GPU the library runs on, held
+ * until the process ends) instead of memory allocated at graph load, and the
+ * call itself allocates and frees nothing.  Graphs of more than
+ * MCX_NOALLOC_MAX_MODULES modules are refused with MCX_E_TOO_LARGE.  Every call
+ * on one GPU uses that GPU's array: calls that overlap on one GPU (two streams,
+ * two contexts) race; calls on one stream are safe.
+ */
+#define MCX_NOALLOC_MAX_MODULES (4u << 20)
+int mcx_dep_flags_noalloc_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags,
+                              void *d_refcnt);
+/*
  * Reachability restricted to LOADED modules.  Bitmaps are ceil(V/32) words,
  * bit v = word v/32, bit v%32.  direction MCX_CLOSURE_HOLDERS: out = seeds'
  * transitive holders (what must be unloaded before the seeds, the situation

@@ -93,6 +93,7 @@ def load_library():
         "mcx_dep_graph_load": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32]),
         "mcx_dep_flags": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
         "mcx_dep_flags_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+        "mcx_dep_flags_noalloc_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
         "mcx_dep_closure": (
             ctypes.c_int,
             [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)],
@@ -337,6 +338,10 @@ class Context:
 
     def dep_flags_dev(self, d_in, d_out, d_ref=None):
         self._check(self.lib.mcx_dep_flags_dev(self.h, d_in, d_out, d_ref), "mcx_dep_flags_dev")
+
+    def dep_flags_noalloc_dev(self, d_in, d_out, d_ref=None):
+        """mcx_dep_flags_dev without any allocation: the bitmap lives in a static device array"""
+        self._check(self.lib.mcx_dep_flags_noalloc_dev(self.h, d_in, d_out, d_ref), "mcx_dep_flags_noalloc_dev")
 
     def dep_closure(self, in_flags, seed_bitmap, direction=CLOSURE_HOLDERS):
         in_flags = _as(in_flags, np.uint8)

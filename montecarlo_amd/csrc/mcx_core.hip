@@ -120,6 +120,10 @@ int mcx_ctx_create(int device_ordinal, void *stream, mcx_ctx **out)
         mcx_ctx_destroy(ctx);
         return MCX_E_NO_DEVICE;
     }
+    if (mcx_k2_static_init(ctx) != MCX_OK) {
+        mcx_ctx_destroy(ctx);
+        return MCX_E_NO_DEVICE;
+    }
     *out = ctx;
     return MCX_OK;
 }

@@ -160,5 +160,8 @@ void mcx_free_table(mcx_ctx *ctx);
 /* d_hw[m] = 1 iff module m < n_modules owns a hardware-bus alias; enqueues */
 int mcx_k1_hw_flags_dev(mcx_ctx *ctx, uint32_t n_modules, uint8_t *d_hw);
 void mcx_free_graph(mcx_ctx *ctx);
+/* device address of the static bitmap of mcx_dep_flags_noalloc_dev on the context's
+ * device (which must be current); called once per context at creation */
+int mcx_k2_static_init(mcx_ctx *ctx);
 
 #endif /* MCX_INTERNAL_H */

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "mcx_internal.h"
@@ -45,11 +46,17 @@ __global__ void __launch_bounds__(K2_THREADS)
 k2_loaded_bitmap(const uint8_t *__restrict__ in_flags, uint32_t V, uint32_t aligned16,
                  uint32_t *__restrict__ bm)
 {
-    /* one thread per bitmap word: 32 flag bytes by two 16-byte loads */
+    /* one thread per bitmap word: 32 flag bytes by two 16-byte loads.  The
+     * readers copy whole 16-byte pieces: the words between the last one in use
+     * and that rounding are written as zero, so that a bitmap buffer that held a
+     * larger graph's bits before shows nothing of them. */
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t v0 = 32u * w;
-    if (v0 >= V)
+    if (v0 >= V) {
+        if (w < ((((V + 31u) / 32u) + 3u) & ~3u))
+            bm[w] = 0u;
         return;
+    }
     uint32_t bits = 0;
     if (aligned16 && v0 + 32u <= V) {
         const uint4 *src = (const uint4 *)(in_flags + v0);
@@ -559,6 +566,45 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
 #define K2B_STATE_WORDS (2u * (K2B_MAX_LEVELS + 1u) + 2u)
 
 /* ------------------------------------------------------------------------- */
+/* LOADED bitmap of mcx_dep_flags_noalloc_dev: a device array of the code      */
+/* object, so that the call needs no allocation.  Every GPU the library runs   */
+/* on holds its own copy at its own address; in host code the array's name is  */
+/* only a handle for hipGetSymbolAddress, never a device address.              */
+/* ------------------------------------------------------------------------- */
+static __device__ __align__(256) uint32_t scratch[MCX_NOALLOC_MAX_MODULES / 32u];
+
+#define K2_MAX_DEVICES 64
+static std::mutex g_scratch_lock;
+static uint32_t *g_scratch_ptr[K2_MAX_DEVICES]; /* device address of `scratch`, per device ordinal */
+
+/* looked up once per device, with that device current (mcx_ctx_create calls this;
+ * the entry point only reads the table) */
+int mcx_k2_static_init(mcx_ctx *ctx)
+{
+    if (ctx->device < 0 || ctx->device >= K2_MAX_DEVICES)
+        return MCX_OK; /* no static bitmap there: the entry point says so */
+    std::lock_guard<std::mutex> guard(g_scratch_lock);
+    if (g_scratch_ptr[ctx->device])
+        return MCX_OK;
+    uint32_t *p = nullptr;
+    HIPCHK(ctx, hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[ctx->device] = p;
+    return MCX_OK;
+}
+
+static uint32_t *k2_static_bitmap(mcx_ctx *ctx)
+{
+    uint32_t *p = nullptr;
+    if (ctx->device >= 0 && ctx->device < K2_MAX_DEVICES) {
+        std::lock_guard<std::mutex> guard(g_scratch_lock);
+        p = g_scratch_ptr[ctx->device];
+    }
+    if (!p)
+        ctx->err = "mcx_dep_flags_noalloc_dev: no static bitmap on device " + std::to_string(ctx->device);
+    return p;
+}
+
+/* ------------------------------------------------------------------------- */
 /* C ABI                                                                      */
 /* ------------------------------------------------------------------------- */
 
@@ -731,22 +777,14 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     return MCX_OK;
 }
 
-int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, void *d_refcnt)
+/* both kernels of K2a with the LOADED bitmap in `bm` (V words' worth of room is not
+ * needed: ceil(V / 32) words rounded up to a multiple of four are used) */
+static int k2_enqueue_flags(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, void *d_refcnt, uint32_t *bm)
 {
-    if (!ctx || !d_in_flags || !d_out_flags)
-        return MCX_E_BAD_ARG;
-    if (!ctx->graph_loaded)
-        return MCX_E_NOT_LOADED;
-    if (ctx->V == 0)
-        return MCX_OK;
-    if (mcx_set_device(ctx))
-        return MCX_E_HIP;
-    /* the bitmap lives in the first frontier queue (V words, idle outside a closure) */
-    uint32_t *bm = ctx->d_queue[0];
-    k2_loaded_bitmap<<<((ctx->V + 31u) / 32u + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
+    const uint32_t W = (ctx->V + 31u) / 32u, W4 = (W + 3u) & ~3u;
+    k2_loaded_bitmap<<<(W4 + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
         (const uint8_t *)d_in_flags, ctx->V, ((uintptr_t)d_in_flags & 15u) == 0u ? 1u : 0u, bm);
     if (ctx->n_cu_part) {
-        const uint32_t W = (ctx->V + 31u) / 32u;
         const size_t lds = 4 * ((size_t)W + ctx->cu_rows_max + 1 + ctx->cu_edges_max / 32 + 8);
         k2_flags_lds<<<ctx->n_cu_part, K2L_THREADS, lds, ctx->stream>>>(
             ctx->d_rrowptr, ctx->d_rcol, ctx->d_cu_part, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
@@ -758,6 +796,43 @@ int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, v
     }
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
+}
+
+int mcx_dep_flags_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, void *d_refcnt)
+{
+    if (!ctx || !d_in_flags || !d_out_flags)
+        return MCX_E_BAD_ARG;
+    if (!ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    if (ctx->V == 0)
+        return MCX_OK;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    /* the bitmap lives in the first frontier queue (V words, idle outside a closure) */
+    return k2_enqueue_flags(ctx, d_in_flags, d_out_flags, d_refcnt, ctx->d_queue[0]);
+}
+
+int mcx_dep_flags_noalloc_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_flags, void *d_refcnt)
+{
+    if (!ctx || !d_in_flags || !d_out_flags)
+        return MCX_E_BAD_ARG;
+    if (!ctx->graph_loaded)
+        return MCX_E_NOT_LOADED;
+    if (ctx->V > MCX_NOALLOC_MAX_MODULES) {
+        ctx->err = "mcx_dep_flags_noalloc_dev: graph of " + std::to_string(ctx->V) + " modules, the static bitmap holds " +
+                   std::to_string(MCX_NOALLOC_MAX_MODULES);
+        return MCX_E_TOO_LARGE;
+    }
+    if (ctx->V == 0)
+        return MCX_OK;
+    if (mcx_set_device(ctx))
+        return MCX_E_HIP;
+    uint32_t *bm = k2_static_bitmap(ctx);
+    if (!bm)
+        return MCX_E_HIP;
+    /* the bitmap kernel writes every word the flag kernel reads, so what the last
+     * call left in the array does not matter */
+    return k2_enqueue_flags(ctx, d_in_flags, d_out_flags, d_refcnt, bm);
 }
 
 int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uint32_t *refcnt)
