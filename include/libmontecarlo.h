@@ -11,10 +11,10 @@
  * meaning "could not tell"; list functions return a count and stop silently when
  * the caller's buffer is full; all buffers are caller allocated.
  *
- * Test seam (not in the reference): when the environment variable
- * MCX_SYSFS_ROOT is set, the absolute paths the library builds itself
- * (/sys/bus/..., /sys/module/..., /proc/modules) are looked up below that
- * directory.  Paths passed in by the caller are used as given.
+ * The shipped library reads no environment variable.  (A separate test build,
+ * compiled with -DMCX_TEST_SEAMS and never installed, looks the absolute paths
+ * the library builds itself - /sys/bus/..., /sys/module/..., /proc/modules - up
+ * below $MCX_SYSFS_ROOT so that tests can walk a fake tree.)
  */
 #ifndef LIBMONTECARLO_H
 #define LIBMONTECARLO_H

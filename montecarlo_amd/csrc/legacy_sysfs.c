@@ -21,6 +21,9 @@
  *   - mc_list_candidate_drivers with max <= 0 writes nothing (the reference
  *     writes one entry before it looks at max);
  *   - mc_get_device_subsystem returns a per-thread buffer, not a process-wide one.
+ * Commands are the reference's own ("modprobe", "dmesg | tail -n 30", found
+ * through PATH by the shell as there); no environment variable names a command
+ * or a path in the shipped build.
  */
 #define _GNU_SOURCE
 #include <dirent.h>
@@ -39,11 +42,20 @@
 
 /* ---- helpers ---------------------------------------------------------------- */
 
-/* "<MCX_SYSFS_ROOT><abs>" */
+/* The absolute /sys and /proc paths the library builds itself.  The shipped
+ * library uses them as they are, like the reference; only the test build
+ * (-DMCX_TEST_SEAMS, a separate file that nothing installs) looks them up below
+ * $MCX_SYSFS_ROOT, so that the tests can walk a fake tree.  This library is
+ * loaded by root processes: no environment variable reaches a path or a command
+ * in the shipped build. */
 static void sys_path(char *out, size_t n, const char *abs)
 {
+#ifdef MCX_TEST_SEAMS
     const char *root = getenv("MCX_SYSFS_ROOT");
     snprintf(out, n, "%s%s", root ? root : "", abs);
+#else
+    snprintf(out, n, "%s", abs);
+#endif
 }
 
 /* what udev_device_get_sysattr_value returns: file content without trailing
@@ -221,8 +233,7 @@ int mc_try_load_driver(const char *driver)
     snprintf(shortname, sizeof shortname, "%s", driver); /* the reference truncates to 63 bytes */
     if (!name_is_safe(shortname, 63))
         return 0;
-    const char *tool = getenv("MCX_MODPROBE");
-    snprintf(cmd, sizeof cmd, "%s %s 2>/dev/null", tool ? tool : "modprobe", shortname);
+    snprintf(cmd, sizeof cmd, "modprobe %s 2>/dev/null", shortname);
     return system(cmd) == 0;
 }
 
@@ -232,8 +243,7 @@ int mc_unload_driver(const char *driver)
     char cmd[512];
     int status = -1;
     if (driver && name_is_safe(driver, 200)) {
-        const char *tool = getenv("MCX_MODPROBE");
-        snprintf(cmd, sizeof cmd, "%s -r %s 2>/dev/null", tool ? tool : "modprobe", driver);
+        snprintf(cmd, sizeof cmd, "modprobe -r %s 2>/dev/null", driver);
         status = system(cmd);
     }
     if (status == -1 || WEXITSTATUS(status) != 0) {
@@ -246,8 +256,9 @@ int mc_unload_driver(const char *driver)
 /* ---- :145-166 ---------------------------------------------------------------- */
 int mc_dmesg_has_activity(const char *driver)
 {
-    const char *cmd = getenv("MCX_DMESG_CMD");
-    FILE *p = popen(cmd ? cmd : "dmesg | tail -n 30", "r");
+    if (!driver)
+        return 0;
+    FILE *p = popen("dmesg | tail -n 30", "r");
     if (!p)
         return 0;
     char line[512];
@@ -373,9 +384,10 @@ int mc_list_all_devices(mc_device_info_t *out, int max)
     static const char *const subsystems[] = {"usb", "pci", "hid", "scsi", "pcmcia", NULL};
     char **paths = NULL;
     size_t npaths = 0, cap = 0;
+    int oom = 0;
     /* what udev_enumerate_scan_devices collects: every entry of
      * /sys/bus/<subsystem>/devices, by its real path, sorted */
-    for (int s = 0; subsystems[s]; ++s) {
+    for (int s = 0; subsystems[s] && !oom; ++s) {
         char abs[128], dirp[PATH_MAX];
         snprintf(abs, sizeof abs, "/sys/bus/%s/devices", subsystems[s]);
         sys_path(dirp, sizeof dirp, abs);
@@ -391,15 +403,34 @@ int mc_list_all_devices(mc_device_info_t *out, int max)
             if (!realpath(link, real) || !is_device(real))
                 continue;
             if (npaths == cap) {
-                cap = cap ? 2 * cap : 64;
-                char **np = (char **)realloc(paths, cap * sizeof *paths);
-                if (!np)
+                const size_t ncap = cap ? 2 * cap : 64;
+                char **np = (char **)realloc(paths, ncap * sizeof *paths);
+                if (!np) {
+                    oom = 1;
                     break;
+                }
                 paths = np;
+                cap = ncap;
             }
-            paths[npaths++] = strdup(real);
+            char *copy = strdup(real);
+            if (!copy) {
+                oom = 1;
+                break;
+            }
+            paths[npaths++] = copy;
         }
         closedir(dir);
+    }
+    if (oom) {
+        /* out of memory while collecting: an empty list, like any other failure */
+        for (size_t i = 0; i < npaths; ++i)
+            free(paths[i]);
+        free(paths);
+        return 0;
+    }
+    if (npaths == 0) {
+        free(paths);
+        return 0;
     }
     qsort(paths, npaths, sizeof *paths, cmp_str);
 

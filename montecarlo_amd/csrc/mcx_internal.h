@@ -47,6 +47,8 @@ struct mcx_ctx {
     uint32_t *d_amod = nullptr;
     uint8_t *d_hwtag = nullptr;
     uint64_t table_bytes = 0;
+    bool bulk_min_set = false;       /* MCX_BULK_MIN was in the environment when the table was loaded */
+    uint32_t bulk_min = 0;
 
     /* dependency graph: forward CSR as given, reverse CSR built at load */
     uint32_t V = 0, E = 0;

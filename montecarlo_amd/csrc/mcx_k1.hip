@@ -1149,6 +1149,11 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
                        sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + t.tags.size() +
                        sizeof(mcx_sub_t) * (uint64_t)t.sub.size() + t.sub_tags.size() + 4 * (uint64_t)P +
                        t.hw_tag.size();
+    {
+        const char *env = getenv("MCX_BULK_MIN");
+        ctx->bulk_min_set = env && *env;
+        ctx->bulk_min = ctx->bulk_min_set ? (uint32_t)strtoul(env, nullptr, 10) : 0u;
+    }
     ctx->table_loaded = true;
     return MCX_OK;
 }
@@ -1190,12 +1195,12 @@ extern "C" int mcx_debug_k1_stamps(unsigned long long *out, uint32_t max_blocks)
  * 3 x 10^6 patterns shares one prefix) that decides it whatever the batch: 1000 strings
  * take 25 us with it and 78 us without (equal at 3 x 10^5 patterns, largest group 11 800);
  * in between, 12 000 strings against 10^5 patterns take 45 us with it and 54 us without.
- * Test seam: MCX_BULK_MIN in the environment replaces the batch size. */
+ * Test seam: MCX_BULK_MIN in the environment, read once when the table is loaded, replaces
+ * the batch size (results do not depend on the variant). */
 static bool k1_use_bulk(const mcx_ctx *ctx, uint32_t N)
 {
-    const char *env = getenv("MCX_BULK_MIN");
-    if (env && *env)
-        return N >= (uint32_t)strtoul(env, nullptr, 10);
+    if (ctx->bulk_min_set)
+        return N >= ctx->bulk_min;
     if (N >= 16384u)
         return true;
     /* the larger the largest group, the earlier the second index pays: 7000 strings against

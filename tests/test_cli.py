@@ -11,12 +11,24 @@ from test_modtab_cpu import ALIAS_TEXT, DEP_TEXT, PROC_MODULES
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CLI = os.path.join(os.path.dirname(HERE), "montecarlo_amd", "lib", "montecarlo_cli")
+# the same tool linked to the test build of the library (the only one that follows MCX_SYSFS_ROOT)
+CLI_SEAMS = CLI + "_testseams"
 
 
-def run(*args, env=None):
+def run(*args, env=None, cli=CLI):
     e = dict(os.environ)
     e.update(env or {})
-    return subprocess.run([CLI, *args], capture_output=True, text=True, env=e, timeout=120)
+    return subprocess.run([cli, *args], capture_output=True, text=True, env=e, timeout=120)
+
+
+def stub_path(tmp_path, exit_code):
+    """a directory with a modprobe that exits with exit_code, to go first in PATH"""
+    d = tmp_path / f"bin{exit_code}"
+    d.mkdir(exist_ok=True)
+    f = d / "modprobe"
+    f.write_text(f"#!/bin/sh\nexit {exit_code}\n")
+    f.chmod(0o755)
+    return f"{d}:{os.environ.get('PATH', '')}"
 
 
 def test_usage_and_unknown_command():
@@ -32,7 +44,7 @@ def test_usage_and_unknown_command():
 
 
 def test_list_is_json_of_the_driver_directories(tree):
-    r = run("list", env={"MCX_SYSFS_ROOT": tree})
+    r = run("list", env={"MCX_SYSFS_ROOT": tree}, cli=CLI_SEAMS)
     assert r.returncode == 0
     names = json.loads(r.stdout)
     assert sorted(names) == sorted(["usb", "hub", "usbhid", "usb-storage", "dummy_hcd", "rtw_8821cu", "hid-generic",
@@ -42,9 +54,9 @@ def test_list_is_json_of_the_driver_directories(tree):
     assert all(ln.endswith(",") for ln in lines[1:-2]) and not lines[-2].endswith(",")
 
 
-def test_load_unload_exit_codes(tree):
-    ok = {"MCX_SYSFS_ROOT": tree, "MCX_MODPROBE": "true"}
-    bad = {"MCX_SYSFS_ROOT": tree, "MCX_MODPROBE": "false"}
+def test_load_unload_exit_codes(tmp_path):
+    ok = {"PATH": stub_path(tmp_path, 0)}
+    bad = {"PATH": stub_path(tmp_path, 1)}
     assert run("load", "e1000", env=ok).returncode == 0
     assert run("load", "e1000", env=bad).returncode == 1
     assert run("unload", "e1000", env=ok).returncode == 0

@@ -18,11 +18,7 @@ class MCDeviceInfo(ctypes.Structure):
                 ("driver", ctypes.c_char * 64), ("subsystem", ctypes.c_char * 16)]
 
 
-@pytest.fixture(scope="module")
-def lib():
-    from montecarlo_amd import binding
-
-    lib = binding.load_library()
+def _declare(lib):
     lib.mc_read_sysattr.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     lib.mc_get_ids.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     lib.mc_get_ids.restype = None
@@ -35,6 +31,44 @@ def lib():
     lib.mc_is_infrastructure_device.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     lib.mc_list_loaded_modules.argtypes = [ctypes.c_char_p, ctypes.c_int]
     return lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    """The test build: the same sources with -DMCX_TEST_SEAMS, the only build in
+    which MCX_SYSFS_ROOT moves the library's /sys and /proc paths (fixture `tree`)."""
+    from montecarlo_amd import binding
+
+    path = os.path.join(os.path.dirname(binding.library_path()), "libmontecarlo_testseams.so")
+    return _declare(ctypes.CDLL(path))
+
+
+@pytest.fixture(scope="module")
+def product_lib():
+    from montecarlo_amd import binding
+
+    return _declare(binding.load_library())
+
+
+@pytest.fixture()
+def stub_tools(tmp_path, monkeypatch):
+    """modprobe / dmesg stand-ins first in PATH: the library runs the reference's own
+    command lines (reference montecarlo/libmontecarlo.c:123,133,147), found through PATH"""
+    bindir = tmp_path / "stubbin"
+    bindir.mkdir()
+    log = tmp_path / "modprobe.log"
+
+    def set_modprobe(exit_code):
+        f = bindir / "modprobe"
+        f.write_text(f"#!/bin/sh\necho \"$@\" >> {log}\nexit {exit_code}\n")
+        f.chmod(0o755)
+
+    d = bindir / "dmesg"
+    d.write_text("#!/bin/sh\nprintf 'usb 1-1: new device\\ne1000: link up\\n'\n")
+    d.chmod(0o755)
+    set_modprobe(0)
+    monkeypatch.setenv("PATH", f"{bindir}:{os.environ.get('PATH', '')}")
+    return set_modprobe, log
 
 
 def test_struct_layout():
@@ -147,23 +181,46 @@ def test_module_state(lib, tree):
     assert lib.mc_list_loaded_modules(small, 8) == 0
 
 
-def test_load_unload_and_dmesg(lib, tree, monkeypatch, capfd):
-    monkeypatch.setenv("MCX_MODPROBE", "true")
-    assert lib.mc_try_load_driver(b"e1000") == 1
-    assert lib.mc_unload_driver(b"e1000") == 1
-    monkeypatch.setenv("MCX_MODPROBE", "false")
-    assert lib.mc_try_load_driver(b"e1000") == 0
-    assert lib.mc_unload_driver(b"e1000") == -1
-    # a name a shell would act on never reaches one
-    monkeypatch.setenv("MCX_MODPROBE", "true")
-    assert lib.mc_try_load_driver(b"e1000; touch /tmp/pwned") == 0
-    assert lib.mc_unload_driver(b"$(reboot)") == -1
-    monkeypatch.setenv("MCX_DMESG_CMD", "printf 'usb 1-1: new device\\ne1000: link up\\n'")
-    assert lib.mc_dmesg_has_activity(b"e1000") == 1
-    assert lib.mc_dmesg_has_activity(b"iwlwifi") == 0
+def test_load_unload_and_dmesg(lib, product_lib, stub_tools, capfd):
+    set_modprobe, log = stub_tools
+    for L in (lib, product_lib):
+        set_modprobe(0)
+        assert L.mc_try_load_driver(b"e1000") == 1
+        assert L.mc_unload_driver(b"e1000") == 1
+        set_modprobe(1)
+        assert L.mc_try_load_driver(b"e1000") == 0
+        assert L.mc_unload_driver(b"e1000") == -1
+        # a name a shell would act on never reaches one
+        set_modprobe(0)
+        assert L.mc_try_load_driver(b"e1000; touch /tmp/pwned") == 0
+        assert L.mc_unload_driver(b"$(reboot)") == -1
+        assert L.mc_dmesg_has_activity(b"e1000") == 1
+        assert L.mc_dmesg_has_activity(b"iwlwifi") == 0
+    # the command lines are the reference's: "modprobe <name>" and "modprobe -r <name>"
+    assert log.read_text().split("\n")[:4] == ["e1000", "-r e1000", "e1000", "-r e1000"]
+    assert "pwned" not in log.read_text() and "reboot" not in log.read_text()
 
 
-def test_real_sysfs_matches_reference_probe(lib, monkeypatch):
+def test_shipped_library_reads_no_environment(lib, product_lib, tree, tmp_path, monkeypatch):
+    """MCX_SYSFS_ROOT moves the test build only; the old command seams are gone from both."""
+    assert lib.mc_module_has_holders(b"snd") == 1          # the fake tree, through the seam
+    if not os.path.isdir("/sys/module/snd/holders"):
+        assert product_lib.mc_module_has_holders(b"snd") == 0   # the real /sys, whatever the variable says
+        assert product_lib.mc_get_module_refcount(b"snd") == -1
+    marker = tmp_path / "ran"
+    monkeypatch.setenv("MCX_MODPROBE", f"touch {marker};")
+    monkeypatch.setenv("MCX_DMESG_CMD", f"touch {marker}")
+    for L in (lib, product_lib):
+        L.mc_try_load_driver(b"no_such_module_xyz")
+        L.mc_dmesg_has_activity(b"no_such_module_xyz")
+    assert not marker.exists()
+    with open(os.path.join(os.path.dirname(__file__), "..", "montecarlo_amd", "lib", "libmontecarlo.so"), "rb") as f:
+        blob = f.read()
+    assert b"MCX_SYSFS_ROOT" not in blob and b"MCX_MODPROBE" not in blob and b"MCX_DMESG_CMD" not in blob
+
+
+def test_real_sysfs_matches_reference_probe(product_lib, monkeypatch):
+    lib = product_lib
     """On this image's own /sys the reference library, when it was built and run
     here during the survey, listed 7 candidate drivers, 6 virtio PCI devices and no
     loaded modules.  Only meaningful where that same /sys is present."""
