@@ -181,10 +181,11 @@ def test_packed_filter_agrees_with_scalar_walk(tree):
     oracle's predicates over records packed from the same tree"""
     import ctypes
 
-    from montecarlo_amd import load_library
+    from montecarlo_amd import binding
     from test_legacy_abi import MCDeviceInfo
 
-    lib = load_library()
+    # the test build of the library: the only one that looks below MCX_SYSFS_ROOT
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(binding.library_path()), "libmontecarlo_testseams.so"))
     lib.mc_list_all_devices.argtypes = [ctypes.POINTER(MCDeviceInfo), ctypes.c_int]
     lib.mc_is_excluded_device.argtypes = [ctypes.c_char_p]
     buf = (MCDeviceInfo * 64)()
