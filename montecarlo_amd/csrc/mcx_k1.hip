@@ -1025,6 +1025,462 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 #endif
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* K1 for large batches: tiles of up to 64 strings per block.                  */
+/* ------------------------------------------------------------------------- */
+/*
+ * What a string costs against a modules.alias-like table is a couple of index
+ * hits, a few dozen candidates and two or three program runs of which one or
+ * two match; a block that owns a handful of strings spends its life in the
+ * latency of those few steps with most lanes idle.  Here a block owns up to 64
+ * strings and every step is a flat pass over work items, a lane per item:
+ *   probe    (string, key length)          -> candidate runs, or a (string,
+ *                                             large group) pair for the second index
+ *   second   (pair, 4-byte window)         -> candidate runs of that group
+ *   screen   one candidate pattern         -> survivors (gram signature inside
+ *                                             the string's gram set)
+ *   run      one survivor                  -> min / count cells of its string
+ * The items wait in bounded LDS queues; a producer step runs only when the
+ * queue behind it has room for the most it can add, otherwise that queue is
+ * drained first, so no table and no batch can overflow them.  Strings stay in
+ * LDS as bytes (any length that fits the staging buffer) and programs are run
+ * position by position: no occurrence tables, which is what lets 64 strings
+ * share a block.
+ */
+#define K1T_THREADS 256u
+#define K1T_WAVES (K1T_THREADS / 64u)
+#define K1T_MAX_SPB 64u
+#define K1T_STR_BYTES 5120u  /* staging buffer of a tile; a tile that needs more is read in place */
+#define K1T_RCAP 1024u       /* candidate runs waiting for the screen (four per thread) */
+#define K1T_BCAP 384u        /* (string, large group) pairs waiting for the second index */
+#define K1T_SCAP 1024u       /* survivors waiting for a program run                  */
+#define K1T_SUB_MAX_LEN 67u  /* strings up to this length go through the second index: one
+                                lane per 4-byte window; longer ones have the whole group screened */
+#define K1T_PAIRS 4u         /* pairs a wave looks up at a time */
+#define K1T_SUB_SPARE (2u * K1T_WAVES * K1T_PAIRS) /* runs a turn adds whatever happens: one for the
+                                patterns without an anchor gram and one fallback per pair */
+
+/* diagnostic builds only (-DK1T_SKIP=n): leave out the phases from n on, to time the rest */
+#ifndef K1T_SKIP
+#define K1T_SKIP 99
+#endif
+
+template <bool LIST>
+__global__ void __launch_bounds__(K1T_THREADS, 4)
+k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
+               uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
+               uint32_t *__restrict__ count, const k1_list_t L)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t str_w[K1T_STR_BYTES / 4u + 8u];
+    __shared__ uint32_t bloom[K1T_MAX_SPB][MCX_BLOOM_WORDS];
+    __shared__ uint32_t str_at[K1T_MAX_SPB], str_len[K1T_MAX_SPB], refused[K1T_MAX_SPB];
+    __shared__ uint32_t res_first[K1T_MAX_SPB], res_count[K1T_MAX_SPB];
+    __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
+    /* candidate runs: first pattern, count (bits 0..25) | string slot (26..31); run_cum = exclusive sums */
+    __shared__ uint32_t run_start[K1T_RCAP], run_cnt[K1T_RCAP], run_cum[K1T_RCAP + 1u];
+    __shared__ uint32_t big_key[K1T_BCAP], big_start[K1T_BCAP], big_count[K1T_BCAP], big_rest[K1T_BCAP];
+    __shared__ uint32_t surv[K1T_SCAP];
+    __shared__ uint32_t nruns_sh, nbig_sh, nsurv_sh, wsum[K1T_WAVES];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t t0 = blockIdx.x * spb;
+    const uint32_t nstr = min(spb, N - t0);
+    const uint32_t gbase = s_off[t0], gend = s_off[t0 + nstr], arena_end = s_off[N];
+    const uint32_t total = gend - gbase;
+    const bool use_lds = total + 3u <= K1T_STR_BYTES;
+    const uint32_t shift = (use_lds && s_aligned) ? (gbase & 3u) : 0u;
+
+    if (tid < T.nlens)
+        key_lens[tid] = T.lens[tid];
+    for (uint32_t i = tid; i < nstr; i += K1T_THREADS) {
+        const uint32_t so = s_off[t0 + i];
+        str_at[i] = so - gbase + shift;
+        str_len[i] = s_off[t0 + i + 1u] - so;
+        res_first[i] = LIST ? L.off[t0 + i] : MCX_NO_MATCH;
+        res_count[i] = 0u;
+        refused[i] = 0u;
+    }
+    for (uint32_t w = tid; w < nstr * MCX_BLOOM_WORDS; w += K1T_THREADS) {
+        /* strings read in place get a full set: their patterns are not screened */
+        uint32_t v = use_lds ? 0u : 0xFFFFFFFFu;
+        if ((w & (MCX_BLOOM_WORDS - 1u)) == (MCX_BLOOM_FREE >> 5))
+            v |= 1u << (MCX_BLOOM_FREE & 31u);
+        bloom[w / MCX_BLOOM_WORDS][w & (MCX_BLOOM_WORDS - 1u)] = v;
+    }
+    if (tid == 0) {
+        nruns_sh = 0;
+        nbig_sh = 0;
+        nsurv_sh = 0;
+    }
+    if (use_lds) {
+        const uint32_t a0 = gbase - shift;
+        const uint32_t nwords = (total + shift + 3u) / 4u + 3u;
+        for (uint32_t w = tid; w < nwords; w += K1T_THREADS) {
+            const uint32_t b0 = a0 + 4u * w;
+            uint32_t v = 0;
+            if (s_aligned && b0 + 4u <= arena_end) {
+                v = *(const uint32_t *)(S + b0);
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (b0 + k < arena_end)
+                        v |= (uint32_t)S[b0 + k] << (8u * k);
+            }
+            str_w[w] = v;
+        }
+    }
+    __syncthreads();
+    if (T.norm_dash) {
+        k1_normalize_tile(str_w, str_at, str_len, refused, nstr, use_lds ? nullptr : S + gbase);
+        __syncthreads();
+    }
+    /* gram sets: a wave per string, a lane per start position */
+    if (use_lds) {
+        for (uint32_t slot = wave; slot < nstr; slot += K1T_WAVES) {
+            const uint32_t len = str_len[slot];
+            const LdsStr str{(lds_words_t)str_w, str_at[slot]};
+            for (uint32_t q = lane; q + 4u <= len; q += 64u) {
+                const uint32_t bit = mcx_gram_bit(str.word(q));
+                atomicOr(&bloom[slot][bit >> 5], 1u << (bit & 31u));
+            }
+        }
+    }
+
+    auto word_of = [&](uint32_t slot, uint32_t q) __attribute__((always_inline)) -> uint32_t {
+        if (use_lds)
+            return LdsStr{(lds_words_t)str_w, str_at[slot]}.word(q);
+        return GlobalStr{S + gbase + str_at[slot], str_len[slot], T.norm_dash}.word(q);
+    };
+    auto push_run = [&](uint32_t start, uint32_t cnt, uint32_t slot) __attribute__((always_inline)) {
+        const uint32_t r = atomicAdd(&nruns_sh, 1u);
+        run_start[r] = start;
+        run_cnt[r] = cnt | (slot << 26);
+    };
+    auto hit = [&](uint32_t slot, uint32_t kk, uint32_t orig, uint32_t mult) __attribute__((always_inline)) {
+        if constexpr (LIST) {
+            if (!refused[slot]) {
+                uint32_t *dst = L.idx + res_first[slot] + atomicAdd(&res_count[slot], mult);
+                if (mult == 1u) {
+                    dst[0] = orig;
+                } else {
+                    const uint32_t *src = L.dup_idx + L.dup_start[kk];
+                    for (uint32_t m = 0; m < mult; ++m)
+                        dst[m] = src[m];
+                }
+            }
+        } else {
+            atomicMin(&res_first[slot], orig);
+            atomicAdd(&res_count[slot], mult);
+        }
+    };
+
+    /* A queue counter as every thread of the block sees it: all appends made so far are
+     * in, and nobody appends again before everybody has read it.  The queues' room is
+     * checked with such reads only, so that the block takes every branch as one. */
+    auto settled = [&](const uint32_t &counter) __attribute__((always_inline)) -> uint32_t {
+        __syncthreads();
+        const uint32_t v = counter;
+        __syncthreads();
+        return v;
+    };
+
+    /* ---- run: a lane per survivor ------------------------------------------ */
+    auto drain_surv = [&]() __attribute__((always_inline)) {
+        /* called by all threads behind a barrier: nsurv_sh is stable */
+        const uint32_t n = K1T_SKIP <= 4 ? 0u : nsurv_sh;
+        for (uint32_t i = tid; i < n; i += K1T_THREADS) {
+            const uint32_t e = surv[i], slot = e >> 26, kk = e & 0x03FFFFFFu;
+            const uint32_t len = str_len[slot];
+            const uint32_t *sp = T.slot + (size_t)kk * MCX_SLOT_WORDS;
+            const uint32_t hdr = sp[0];
+            const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
+            const FlatProg fp{is_ext ? T.ext : sp};
+            const uint32_t at = is_ext ? sp[MCX_SLOT_DIR] : MCX_SLOT_BODY;
+            bool ok;
+            if (use_lds)
+                ok = mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets);
+            else
+                ok = mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len, T.norm_dash}, len, T.sets);
+            if (ok)
+                hit(slot, kk, sp[1], sp[MCX_SLOT_MULT]);
+        }
+        __syncthreads();
+        if (tid == 0)
+            nsurv_sh = 0;
+        __syncthreads();
+    };
+
+    /* ---- screen: a lane per candidate of the queued runs -------------------- */
+    auto drain_runs = [&]() __attribute__((always_inline)) {
+        /* called by all threads behind a barrier */
+        const uint32_t nr = K1T_SKIP <= 3 ? 0u : nruns_sh;
+        /* exclusive sums of the run sizes, four runs per thread */
+        {
+            uint32_t c[4], mine = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t r = 4u * tid + k;
+                c[k] = r < nr ? (run_cnt[r] & 0x03FFFFFFu) : 0u;
+                mine += c[k];
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d)
+                    incl += o;
+            }
+            if (lane == 63u)
+                wsum[wave] = incl;
+            __syncthreads();
+            uint32_t at = incl - mine;
+#pragma unroll
+            for (uint32_t k = 0; k < K1T_WAVES; ++k)
+                if (k < wave)
+                    at += wsum[k];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                run_cum[4u * tid + k] = at;
+                at += c[k];
+            }
+            if (tid == K1T_THREADS - 1u)
+                run_cum[K1T_RCAP] = at; /* K1T_RCAP = 4 x K1T_THREADS: the sum over all entries */
+            __syncthreads();
+        }
+        const uint32_t ncand = run_cum[nr];
+        uint32_t bound = nsurv_sh; /* no more survivors than this are queued */
+        for (uint32_t c0 = 0; c0 < ncand; c0 += K1T_THREADS) {
+            if (bound + K1T_THREADS > K1T_SCAP) {
+                bound = settled(nsurv_sh);
+                if (bound + K1T_THREADS > K1T_SCAP) {
+                    drain_surv();
+                    bound = 0;
+                }
+            }
+            const uint32_t c = c0 + tid;
+            bool pass = false;
+            uint32_t e = 0;
+            if (c < ncand) {
+                /* the run that holds candidate c: largest r with run_cum[r] <= c */
+                uint32_t lo = 0, hi = nr;
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (run_cum[mid] <= c)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint32_t k = run_start[lo] + (c - run_cum[lo]), slot = run_cnt[lo] >> 26;
+                const uint32_t sg = T.sig[k];
+                const uint32_t *bl = bloom[slot];
+                uint32_t all = 1u;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const uint32_t bit = (sg >> (8u * j)) & 0xFFu;
+                    all &= bl[bit >> 5] >> (bit & 31u);
+                }
+                pass = (all & 1u) != 0u;
+                e = (slot << 26) | k;
+            }
+            const unsigned long long bm = __ballot(pass);
+            if (bm) {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&nsurv_sh, (uint32_t)__popcll(bm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (pass)
+                    surv[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = e;
+            }
+            bound += K1T_THREADS;
+        }
+        __syncthreads();
+        if (tid == 0)
+            nruns_sh = 0;
+        __syncthreads();
+    };
+
+    /* ---- second index: a wave per (string, large group), a lane per window -- */
+    auto drain_big = [&]() __attribute__((always_inline)) {
+        /* called by all threads behind a barrier.  A wave takes K1T_PAIRS pairs per turn: the
+         * words, hashes and tag bytes of all of them are under way before the first answer is
+         * looked at.  The runs a pair finds are queued all or none (one reservation per pair);
+         * when the queue has no room for them the group's indexed part goes in as one run, which
+         * costs time, not correctness.  K1T_SUB_SPARE entries are kept for those single runs. */
+        const uint32_t nb = K1T_SKIP <= 2 ? 0u : nbig_sh;
+        for (uint32_t b0 = 0; b0 < nb; b0 += K1T_WAVES * K1T_PAIRS) {
+            if (settled(nruns_sh) + K1T_SUB_SPARE + K1T_THREADS > K1T_RCAP)
+                drain_runs(); /* ends with a barrier */
+            uint32_t w[K1T_PAIRS], h[K1T_PAIRS], tag[K1T_PAIRS], key[K1T_PAIRS];
+            bool act[K1T_PAIRS];
+#pragma unroll
+            for (uint32_t i = 0; i < K1T_PAIRS; ++i) {
+                const uint32_t b = b0 + K1T_PAIRS * wave + i;
+                act[i] = false;
+                w[i] = h[i] = tag[i] = 0u;
+                key[i] = 0xFFFFFFFFu;
+                if (b < nb) {
+                    key[i] = big_key[b];
+                    const uint32_t slot = key[i] & 63u;
+                    if (lane + 4u <= str_len[slot]) {
+                        act[i] = true;
+                        w[i] = word_of(slot, lane);
+                        h[i] = mcx_sub_hash(w[i], key[i] >> 6);
+                        tag[i] = T.sub_tags[h[i] & T.sub_mask];
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < K1T_PAIRS; ++i) {
+                const uint32_t b = b0 + K1T_PAIRS * wave + i;
+                if (b >= nb)
+                    break; /* the same for the whole wave */
+                bool found = false;
+                uint32_t fstart = 0, fcnt = 0;
+                if (act[i]) {
+                    const uint32_t tg = mcx_key_tag(h[i]), gid = key[i] >> 6;
+                    uint32_t t = tag[i];
+                    for (uint32_t p = h[i] & T.sub_mask; t != 0u; p = (p + 1u) & T.sub_mask, t = T.sub_tags[p]) {
+                        if (t != tg)
+                            continue;
+                        const mcx_sub_t en = T.sub[p];
+                        if (en.gram == w[i] && en.gid == gid) {
+                            found = true;
+                            fstart = en.start;
+                            fcnt = en.count;
+                            break;
+                        }
+                    }
+                }
+                /* a gram that occurs twice in the string names its run once: the lowest lane
+                 * holding these four bytes keeps it */
+                unsigned long long todo = __ballot(found);
+                while (todo) {
+                    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(todo));
+                    const uint32_t wl = __builtin_amdgcn_readlane(w[i], l);
+                    const unsigned long long same = __ballot(act[i] && w[i] == wl);
+                    if (lane == l && (uint32_t)__builtin_ctzll(same) != l)
+                        found = false;
+                    todo &= ~(1ull << l);
+                }
+                const unsigned long long fm = __ballot(found);
+                const uint32_t nf = (uint32_t)__popcll(fm), slot = key[i] & 63u;
+                const uint32_t rest = big_rest[b], gstart = big_start[b], gcount = big_count[b];
+                uint32_t base = 0xFFFFFFFFu;
+                if (lane == 0u) {
+                    if (rest != 0u)
+                        push_run(gstart, rest, slot);
+                    if (nf != 0u) {
+                        uint32_t old = nruns_sh;
+                        for (;;) {
+                            if (old + nf > K1T_RCAP - K1T_SUB_SPARE)
+                                break;
+                            const uint32_t seen = atomicCAS(&nruns_sh, old, old + nf);
+                            if (seen == old) {
+                                base = old;
+                                break;
+                            }
+                            old = seen;
+                        }
+                        if (base == 0xFFFFFFFFu)
+                            push_run(gstart + rest, gcount - rest, slot);
+                    }
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (found && base != 0xFFFFFFFFu) {
+                    const uint32_t r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                    run_start[r] = fstart;
+                    run_cnt[r] = fcnt | (slot << 26);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0)
+            nbig_sh = 0;
+        __syncthreads();
+    };
+
+    /* ---- probe: a lane per (string, key length) ------------------------------ */
+    __syncthreads();
+    const uint32_t nprobe = K1T_SKIP <= 1 ? 0u : nstr * T.nlens;
+    uint32_t rbound = 0, bbound = 0; /* no more runs / pairs than these are queued */
+    for (uint32_t p0 = 0; p0 < nprobe; p0 += K1T_THREADS) {
+        /* a step adds at most one run or one pair per lane */
+        if (bbound + K1T_THREADS > K1T_BCAP) {
+            bbound = settled(nbig_sh);
+            if (bbound + K1T_THREADS > K1T_BCAP) {
+                drain_big(); /* ends with a barrier */
+                bbound = 0;
+                rbound = K1T_RCAP; /* unknown now: looked up below */
+            }
+        }
+        if (rbound + K1T_THREADS > K1T_RCAP) {
+            rbound = settled(nruns_sh);
+            if (rbound + K1T_THREADS > K1T_RCAP) {
+                drain_runs();
+                rbound = 0;
+            }
+        }
+        rbound += K1T_THREADS;
+        bbound += K1T_THREADS;
+        const uint32_t pr = p0 + tid;
+        if (pr < nprobe) {
+            const uint32_t slot = T.nlens == 1u ? pr : __umulhi(pr, T.nlens_magic), KL = key_lens[pr - slot * T.nlens];
+            const uint32_t len = str_len[slot];
+            if (KL <= len) {
+                uint32_t kw[MCX_KEY_MAX / 4];
+#pragma unroll
+                for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                    kw[k] = (4u * k < KL) ? word_of(slot, 4u * k) : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                    if ((KL >> 2) == k && (KL & 3u))
+                        kw[k] &= 0xFFFFFFFFu >> (8u * (4u - (KL & 3u)));
+                const uint32_t a = mcx_key_hash(kw, KL), my_tag = mcx_key_tag(a);
+                for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
+                    const uint32_t tag = T.tags[at];
+                    if (tag == 0u)
+                        break;
+                    if (tag != my_tag)
+                        continue;
+                    const mcx_slot_t sl = T.slots[at];
+                    bool same = sl.hash == a && sl.len == KL;
+#pragma unroll
+                    for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                        same = same && sl.key[k] == kw[k];
+                    if (same) {
+                        if (sl.pad[0] != 0u && use_lds && len <= K1T_SUB_MAX_LEN) {
+                            const uint32_t bi = atomicAdd(&nbig_sh, 1u);
+                            big_key[bi] = slot | ((sl.pad[0] - 1u) << 6);
+                            big_start[bi] = sl.start;
+                            big_count[bi] = sl.count;
+                            big_rest[bi] = sl.pad[1];
+                        } else {
+                            push_run(sl.start, sl.count, slot);
+                        }
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    if (settled(nbig_sh) != 0u)
+        drain_big();
+    if (settled(nruns_sh) != 0u)
+        drain_runs();
+    if (settled(nsurv_sh) != 0u)
+        drain_surv();
+    if constexpr (!LIST) {
+        for (uint32_t i = tid; i < nstr; i += K1T_THREADS) {
+            first_idx[t0 + i] = refused[i] ? MCX_NO_MATCH : res_first[i];
+            count[t0 + i] = refused[i] ? 0u : res_count[i];
+        }
+    }
+}
+
 /* one thread per string: its list in ascending table order (lists are short:
  * a handful of entries; insertion sort in place) */
 __global__ void __launch_bounds__(256)
@@ -1153,6 +1609,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
         const char *env = getenv("MCX_BULK_MIN");
         ctx->bulk_min_set = env && *env;
         ctx->bulk_min = ctx->bulk_min_set ? (uint32_t)strtoul(env, nullptr, 10) : 0u;
+        const char *tiles = getenv("MCX_K1_TILES");
+        ctx->k1_tiles = !(tiles && tiles[0] == '0');
     }
     ctx->table_loaded = true;
     return MCX_OK;
@@ -1248,6 +1706,25 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
      * has larger hit arrays; the staging buffer then gives way (down to 128 bytes per string)
      * so that the fifth block still fits. */
     const bool bulk = k1_use_bulk(ctx, N);
+    const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
+#ifndef MCX_K1_STAMPS
+    if (bulk && ctx->k1_tiles) {
+        /* tiles of up to 64 strings, as many as leave every CU a few blocks */
+        uint32_t tspb = (N + 2047u) / 2048u;
+        if (tspb > K1T_MAX_SPB)
+            tspb = K1T_MAX_SPB;
+        const uint32_t tblocks = (N + tspb - 1u) / tspb;
+        const k1_list_t TL{d_list_off, d_list_idx, ctx->d_dup_start, ctx->d_dup_idx};
+        if (d_list_off)
+            k1_match_tiles<true><<<tblocks, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, tspb, s_aligned, T,
+                                                                           nullptr, nullptr, TL);
+        else
+            k1_match_tiles<false><<<tblocks, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, tspb, s_aligned, T,
+                                                                            d_first, d_count, TL);
+        HIPCHK(ctx, hipGetLastError());
+        return MCX_OK;
+    }
+#endif
     uint32_t sub_cap = 0; /* entries for the runs found through the second index (large batches) */
     auto lds_bytes = [&](uint32_t cap, uint32_t subs) {
         return 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)cap / 4 + 5 + 3 * (size_t)spb * T.nlens + 2 * (size_t)subs + 1);
@@ -1271,7 +1748,6 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         }
     }
     size_t lds = lds_bytes(str_cap, sub_cap);
-    const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
 #ifdef MCX_K1_STAMPS
     static uint32_t stamp_cap = 0;
     if (blocks > stamp_cap) {
