@@ -1,17 +1,19 @@
 """Benchmark of the batch hot path on MI355X.
 
-One step = one pass of the alias matcher (K1) over one batch of synthetic
-modalias strings that are already resident in HBM: configs[1] of the benchmark definition,
-1000 strings x 30000 alias patterns, seed 2.  With --gpus N (launched through
-torch.distributed.run, one rank per GPU) every rank matches its own 1000-string
-shard of a 1000*N batch against its own copy of the table: the path shards by
-string with no data-path collective, so scaling is weak.
-
-Prints ONE JSON line (rank 0).  Beside the headline value it carries
+One GPU (the default): one step = one pass of the alias matcher (K1) over one batch of
+synthetic modalias strings already resident in HBM - configs[1] of the benchmark definition,
+1000 strings x 30000 alias patterns, seed 2.  Beside the headline value the line carries
   roofline      algorithmic bytes of one K1 launch / measured device time
   cpu_baseline  the CPU oracle (glibc fnmatch loop) timed on the host cores
   k2            dependency flags + closure on configs[2] (1M modules, ~10M edges)
   fleet         the fused inventory pipeline on configs[4] (100000 hosts, ~10M devices)
+  configs3      1M strings x 3M patterns on this one GPU
+
+--gpus N > 1 (launched through torch.distributed.run, one rank per GPU): configs[3], the alias
+table cut into N slices, all strings against every slice, MIN / SUM all-reduce over RCCL per
+step; the collective alone, the string-sharded layout and the one-GPU time are in the same line.
+
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -38,9 +40,12 @@ def parse():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--graph-vertices", type=int, default=1_000_000)
     ap.add_argument("--graph-degree", type=int, default=10)
-    ap.add_argument("--shard", choices=["strings", "patterns"], default="strings",
-                    help="with --gpus N>1: every rank its own strings against the whole table (default, no "
-                         "collective), or every rank a slice of the table against all strings + MIN/SUM all-reduce")
+    ap.add_argument("--repeats", type=int, default=31,
+                    help="one GPU: how many brackets of --steps steps are timed; the median one is reported")
+    ap.add_argument("--c3-strings", type=int, default=1_000_000, help="configs[3]: strings")
+    ap.add_argument("--c3-patterns", type=int, default=3_000_000, help="configs[3]: alias patterns")
+    ap.add_argument("--c3-cpu-strings", type=int, default=128, help="configs[3]: strings of the CPU sample")
+    ap.add_argument("--no-configs3", action="store_true")
     ap.add_argument("--no-k2", action="store_true")
     ap.add_argument("--no-fleet", action="store_true")
     ap.add_argument("--fleet-hosts", type=int, default=100_000)
@@ -152,6 +157,19 @@ def cpu_baseline_k1(A, a_off, S, s_off, budget_s):
     return res
 
 
+def bracket(step, fence, ctx, steps):
+    """EXACTLY `steps` steps between two fences (barrier + torch.cuda.synchronize); returns
+    (wall seconds, device milliseconds from HIP events on the context's stream)"""
+    fence()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    for _ in range(steps):
+        step()
+    dev_ms = ctx.timer_end()
+    fence()
+    return time.perf_counter() - t0, dev_ms
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -182,133 +200,317 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     stream = torch.cuda.Stream(device=local_rank)
-
-    N, P = args.strings, args.patterns
-    by_pattern = world > 1 and args.shard == "patterns"
-    from montecarlo_amd import shard
-
-    if by_pattern:
-        # configs[3] layout: rank r holds table slice [j0, j1) and sees all N strings
-        j0, j1 = shard.shard_range(P, rank, world)
-        A, a_off, a_mod = synth.alias_table(args.seed, P, j0, j1)
-        S, s_off = synth.modalias_strings(args.seed, P, N)
-    else:
-        # rank r owns strings [r*N, (r+1)*N) of the N*world batch, whole table everywhere
-        j0 = 0
-        A, a_off, a_mod = synth.alias_table(args.seed, P)
-        S, s_off = synth.modalias_strings(args.seed, P, N * world, i0=rank * N, i1=(rank + 1) * N)
-
     ctx = Context(local_rank, stream=stream.cuda_stream)
-    ctx.alias_table_load(A, a_off, a_mod)
-    d_S, d_off = ctx.to_device(S), ctx.to_device(s_off)
-    # outputs live in torch tensors so that the pattern-sharded mode can all-reduce them in place
-    t_first = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
-    t_count = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
-
-    def step():
-        ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, t_first.data_ptr(), t_count.data_ptr())
-        if by_pattern and rehearse:
-            # gloo reduces host tensors: the rehearsal takes the results through the host
-            stream.synchronize()
-            f, c = t_first.cpu(), t_count.cpu()
-            shard.combine_pattern_shards(f, c, j0)
-            t_first.copy_(f)
-            t_count.copy_(c)
-        elif by_pattern:
-            with torch.cuda.stream(stream):
-                shard.combine_pattern_shards(t_first, t_count, j0)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    ctx.timer_begin()
-    for _ in range(args.steps):
-        step()
-    dev_ms = ctx.timer_end()  # HIP events on the stream the kernels run on
-    fence()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
-
-    # results of the last step must be the oracle's (cheap: a 64-string sample)
-    first = shard.as_u32(t_first)
-    count = shard.as_u32(t_count)
-
-    out = None
-    if rank == 0:
-        pairs_per_step = N * P if by_pattern else N * P * world
-        alg_bytes = k1_algorithmic_bytes(S, s_off, A, a_off)
-        dev_s_per_launch = dev_ms / 1e3 / args.steps
-        achieved = alg_bytes / dev_s_per_launch / 1e9
-        out = {
-            "metric": "device x alias glob matches/sec + dep-closure edges/sec, 1 GPU vs host C",
-            "value": pairs_per_step * args.steps / wall,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps,
-            "higher_is_better": True,
-            "scaling": "strong" if by_pattern else "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": (f"configs[3] layout: {N} modalias strings x {P} alias patterns, table cut in {world} "
-                             f"slices, MIN/SUM all-reduce per step, seed {args.seed}") if by_pattern else
-                            (f"configs[1]: {N} modalias strings x {P} alias patterns per GPU, seed {args.seed}, "
-                             "strings and table resident in HBM"),
-                "strings_per_gpu": N,
-                "patterns": P,
-                "sharding": ("patterns" if by_pattern else "strings") if world > 1 else "none",
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(N, P),
-                "kernel": "k1_match_indexed, one launch per step, device time from HIP events on its stream",
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "device_us_per_launch": dev_s_per_launch * 1e6,
-            },
-            "matched_strings": int((count > 0).sum()),
-        }
-
-    # the K2 and fleet blocks are one-GPU measurements: the scaling runs do not repeat them
     if world > 1:
-        args.no_k2 = args.no_fleet = True
-    if rank == 0 and not args.no_k2:
-        out["k2"] = bench_k2(ctx, synth, args, with_cpu=not args.no_cpu and world == 1)
-    if rank == 0 and not args.no_fleet:
-        out["fleet"] = bench_fleet(ctx, synth, args, with_cpu=not args.no_cpu and world == 1)
-    if rank == 0 and not args.no_cpu and world == 1:
-        import oracle
-
-        n_chk = min(N, 64)
-        if by_pattern:  # the combined result is against the whole table
-            A, a_off, a_mod = synth.alias_table(args.seed, P)
-        o_first, o_count = oracle.alias_match(A, a_off, S, s_off, i0=0, i1=n_chk)
-        if not (np.array_equal(first[:n_chk], o_first) and np.array_equal(count[:n_chk], o_count)):
-            raise SystemExit("bench: GPU result differs from the oracle")
-        out["cpu_baseline"] = cpu_baseline_k1(A, a_off, S, s_off, args.cpu_seconds)
-    for b in (d_S, d_off):
-        b.free()
+        out = bench_sharded(ctx, synth, args, torch, dist, stream, fence, rank, world, local_rank, rehearse)
+    else:
+        out = bench_one_gpu(ctx, synth, args, torch, stream, fence, local_rank)
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+METRIC = "device x alias glob matches/sec + dep-closure edges/sec, 1 GPU vs host C"
+
+
+def bench_one_gpu(ctx, synth, args, torch, stream, fence, local_rank):
+    """configs[1]: the headline line, and beside it the blocks for configs[2], [3] and [4]"""
+    N, P = args.strings, args.patterns
+    A, a_off, a_mod = synth.alias_table(args.seed, P)
+    S, s_off = synth.modalias_strings(args.seed, P, N)
+    ctx.alias_table_load(A, a_off, a_mod)
+    d_S, d_off = ctx.to_device(S), ctx.to_device(s_off)
+    t_first = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
+    t_count = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
+
+    def step():
+        ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, t_first.data_ptr(), t_count.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    # A bracket of K steps of 10 us each is a fraction of a millisecond: one alone is at the mercy
+    # of a single host hiccup.  The bracket is repeated and the median one is reported.
+    runs = sorted(bracket(step, fence, ctx, args.steps) for _ in range(max(1, args.repeats)))
+    wall, dev_ms = runs[len(runs) // 2]
+    from montecarlo_amd import shard
+
+    first, count = shard.as_u32(t_first), shard.as_u32(t_count)
+    alg_bytes = k1_algorithmic_bytes(S, s_off, A, a_off)
+    dev_s_per_launch = dev_ms / 1e3 / args.steps
+    achieved = alg_bytes / dev_s_per_launch / 1e9
+    out = {
+        "metric": METRIC,
+        "value": N * P * args.steps / wall,
+        "unit": "pairs/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[1]: {N} modalias strings x {P} alias patterns, seed {args.seed}, "
+                        "strings and table resident in HBM",
+            "strings_per_gpu": N,
+            "patterns": P,
+            "sharding": "none",
+        },
+        "timing": {
+            "brackets": len(runs),
+            "reported": "median bracket of `steps` steps (each between barrier + synchronize)",
+            "ms_per_step_min": runs[0][0] * 1e3 / args.steps,
+            "ms_per_step_max": runs[-1][0] * 1e3 / args.steps,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": measured_traffic(N, P),
+            "kernel": "k1_match_indexed, one launch per step, device time from HIP events on its stream",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "device_us_per_launch": dev_s_per_launch * 1e6,
+        },
+        "matched_strings": int((count > 0).sum()),
+    }
+    if not args.no_cpu:
+        import oracle
+
+        n_chk = min(N, 64)
+        o_first, o_count = oracle.alias_match(A, a_off, S, s_off, i0=0, i1=n_chk)
+        if not (np.array_equal(first[:n_chk], o_first) and np.array_equal(count[:n_chk], o_count)):
+            raise SystemExit("bench: GPU result differs from the oracle")
+        out["cpu_baseline"] = cpu_baseline_k1(A, a_off, S, s_off, args.cpu_seconds)
+    for b in (d_S, d_off):
+        b.free()
+    if not args.no_k2:
+        out["k2"] = bench_k2(ctx, synth, args, with_cpu=not args.no_cpu)
+    if not args.no_fleet:
+        out["fleet"] = bench_fleet(ctx, synth, args, with_cpu=not args.no_cpu)
+    if not args.no_configs3:
+        out["configs3"] = bench_configs3(ctx, synth, args, with_cpu=not args.no_cpu)
+    return out
+
+
+def configs3_inputs(synth, args, j0=0, j1=None):
+    P, N, seed = args.c3_patterns, args.c3_strings, 4
+    A, a_off, a_mod = synth.alias_table(seed, P, j0, P if j1 is None else j1)
+    S, s_off = synth.modalias_strings(seed, P, N)
+    return A, a_off, a_mod, S, s_off
+
+
+def bench_configs3(ctx, synth, args, with_cpu=False):
+    """configs[3] on ONE GPU: the whole 3M-pattern table against the whole 1M-string batch (it
+    fits: half a gigabyte).  The CPU side is a sample, extrapolated and labelled so."""
+    P, N = args.c3_patterns, args.c3_strings
+    t0 = time.perf_counter()
+    A, a_off, a_mod, S, s_off = configs3_inputs(synth, args)
+    gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ctx.alias_table_load(A, a_off, a_mod)
+    load_s = time.perf_counter() - t0
+    d_S, d_off = ctx.to_device(S), ctx.to_device(s_off)
+    d_f, d_c = ctx.alloc(4 * N), ctx.alloc(4 * N)
+    for _ in range(2):
+        ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, d_f.ptr, d_c.ptr)
+    ctx.sync()
+    reps = 5
+    ctx.timer_begin()
+    for _ in range(reps):
+        ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, d_f.ptr, d_c.ptr)
+    ms = ctx.timer_end() / reps
+    first, count = d_f.download(np.uint32, N), d_c.download(np.uint32, N)
+    alg = k1_algorithmic_bytes(S, s_off, A, a_off)
+    res = {
+        "workload": f"configs[3] on one GPU: {N} modalias strings x {P} alias patterns, seed 4, resident in HBM",
+        "ms_per_pass": ms,
+        "pairs_per_s": N * P / (ms / 1e3),
+        "algorithmic_bytes": alg,
+        "achieved_GBs": alg / (ms / 1e3) / 1e9,
+        "frac_of_hbm_peak": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+        "matched_strings": int((count > 0).sum()),
+        "host_seconds": {"generate_inputs": gen_s, "compile_and_load_table": load_s},
+    }
+    if with_cpu:
+        import oracle
+
+        # glibc loop: about 0.1 s per string against 3M patterns; a sample on all cores, extrapolated
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        per = max(1, int(args.c3_cpu_strings) // cores)
+        n_s = per * cores
+        got = [None] * cores
+
+        def work(k):
+            got[k] = oracle.alias_match(A, a_off, S, s_off, i0=k * per, i1=(k + 1) * per)
+
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        o_first = np.concatenate([g[0] for g in got])
+        o_count = np.concatenate([g[1] for g in got])
+        if not (np.array_equal(first[:n_s], o_first) and np.array_equal(count[:n_s], o_count)):
+            raise SystemExit("bench: configs[3] result differs from the oracle")
+        res["cpu_baseline"] = {
+            "value": n_s * P / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"the first {n_s} of the {N} strings through the glibc fnmatch loop against all {P} "
+                      f"patterns, {cores} threads, {el:.1f} s; EXTRAPOLATED to the whole batch: "
+                      f"{el * N / n_s / 3600:.1f} hours",
+            "extrapolated_seconds_per_pass": el * N / n_s,
+        }
+    for b in (d_S, d_off, d_f, d_c):
+        b.free()
+    return res
+
+
+def bench_sharded(ctx, synth, args, torch, dist, stream, fence, rank, world, local_rank, rehearse):
+    """--gpus N > 1: configs[3], 1M strings x 3M patterns.  Headline: the alias table cut into N
+    contiguous slices (one per GPU), every GPU matching all strings against its slice, one MIN and
+    one SUM all-reduce of 1M words per step over RCCL.  Beside it in the same line: the collective
+    alone, the kernel alone, the string-sharded layout (whole table everywhere, no collective) and,
+    on rank 0, the whole problem on one GPU."""
+    from montecarlo_amd import shard
+
+    P, N = args.c3_patterns, args.c3_strings
+    dev = f"cuda:{local_rank}"
+    j0, j1 = shard.shard_range(P, rank, world)
+    A, a_off, a_mod, S, s_off = configs3_inputs(synth, args, j0, j1)
+    ctx.alias_table_load(A, a_off, a_mod)
+    d_S, d_off = ctx.to_device(S), ctx.to_device(s_off)
+    t_first = torch.empty(N, dtype=torch.int32, device=dev)
+    t_count = torch.empty(N, dtype=torch.int32, device=dev)
+
+    def combine():
+        if rehearse:  # gloo reduces host tensors: the rehearsal takes the results through the host
+            stream.synchronize()
+            f, c = t_first.cpu(), t_count.cpu()
+            shard.combine_pattern_shards(f, c, j0)
+            t_first.copy_(f)
+            t_count.copy_(c)
+        else:
+            with torch.cuda.stream(stream):
+                shard.combine_pattern_shards(t_first, t_count, j0)
+
+    def match():
+        ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, t_first.data_ptr(), t_count.data_ptr())
+
+    def step():
+        match()
+        combine()
+
+    def maxed(*vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    for _ in range(args.warmup):
+        step()
+    wall, dev_ms = maxed(*bracket(step, fence, ctx, args.steps))
+    first, count = shard.as_u32(t_first).copy(), shard.as_u32(t_count).copy()
+    k_wall, k_dev_ms = maxed(*bracket(match, fence, ctx, args.steps))   # the kernel alone
+    c_wall, c_dev_ms = maxed(*bracket(combine, fence, ctx, args.steps))  # the two all-reduces alone
+    alg_bytes = k1_algorithmic_bytes(S, s_off, A, a_off)
+    k_s = k_dev_ms / 1e3 / args.steps
+    out = {
+        "metric": METRIC,
+        "value": N * P * args.steps / wall,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[3]: {N} modalias strings x {P} alias patterns, seed 4, alias table cut into "
+                        f"{world} contiguous slices (one per GPU), MIN + SUM all-reduce of {N} words per step",
+            "strings": N,
+            "patterns": P,
+            "sharding": "patterns",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": alg_bytes / k_s / 1e9,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": alg_bytes / k_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "k1_match_tiles on this rank's table slice, device time from HIP events, max over ranks",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "device_us_per_launch": k_s * 1e6,
+        },
+        "pattern_sharded": {
+            "ms_per_step": wall * 1e3 / args.steps,
+            "kernel_alone_ms": k_wall * 1e3 / args.steps,
+            "allreduce_alone_ms": c_wall * 1e3 / args.steps,
+            "allreduce_bytes_per_step": 8 * N,
+        },
+        "matched_strings": int((count > 0).sum()),
+    }
+    # the other layout: whole table on every GPU, every GPU its own N / world strings, no collective
+    for b in (d_S, d_off):
+        b.free()
+    A, a_off, a_mod, S_all, s_all = configs3_inputs(synth, args)
+    ctx.alias_table_load(A, a_off, a_mod)
+    i0, i1 = shard.shard_range(N, rank, world)
+    S_r, s_r = synth.modalias_strings(4, P, N, i0=i0, i1=i1)
+    d_S, d_off = ctx.to_device(S_r), ctx.to_device(s_r)
+    n_r = i1 - i0
+
+    def match_own():
+        ctx.alias_match_dev(d_S.ptr, d_off.ptr, n_r, t_first.data_ptr(), t_count.data_ptr())
+
+    for _ in range(args.warmup):
+        match_own()
+    s_wall, _ = maxed(*bracket(match_own, fence, ctx, args.steps))
+    own_first = shard.as_u32(t_first)[:n_r].copy()
+    out["string_sharded"] = {
+        "value": N * P * args.steps / s_wall, "unit": "pairs/s", "ms_per_step": s_wall * 1e3 / args.steps,
+        "note": "whole table on every GPU, N / n_gpus strings each, no data-path collective",
+        "same_results_as_pattern_sharded": bool(np.array_equal(own_first, first[i0:i1])),
+    }
+    for b in (d_S, d_off):
+        b.free()
+    if rank == 0:
+        # one GPU, whole problem: the reference the sharded figures are speed-ups of
+        d_S, d_off = ctx.to_device(S_all), ctx.to_device(s_all)
+
+        def match_all():
+            ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, t_first.data_ptr(), t_count.data_ptr())
+
+        match_all()
+        ctx.sync()
+        ctx.timer_begin()
+        for _ in range(3):
+            match_all()
+        one_ms = ctx.timer_end() / 3
+        same = np.array_equal(shard.as_u32(t_first), first) and np.array_equal(shard.as_u32(t_count), count)
+        out["one_gpu"] = {"ms_per_pass": one_ms, "value": N * P / (one_ms / 1e3), "unit": "pairs/s",
+                          "same_results_as_pattern_sharded": bool(same)}
+        out["pattern_sharded"]["speedup_vs_one_gpu"] = one_ms / (wall * 1e3 / args.steps)
+        out["string_sharded"]["speedup_vs_one_gpu"] = one_ms / (s_wall * 1e3 / args.steps)
+        for b in (d_S, d_off):
+            b.free()
+    return out
 
 
 def bench_k2(ctx, synth, args, with_cpu=False):
@@ -344,21 +546,37 @@ def bench_k2(ctx, synth, args, with_cpu=False):
             "traffic": measured_traffic_k2(alg_flags),
         },
     }
-    for name, direction in (("closure_holders", 0), ("closure_deps", 1)):
-        ctx.dep_closure_dev(d_in.ptr, d_seed.ptr, d_clo.ptr, direction)
+    # closure: 16 seeds (what an operator asks for one device's drivers: latency bound) and the
+    # large-frontier case, seeds = every BOUND module (in the deps direction that is the set of
+    # modules that cannot be unloaded safely)
+    bound_seeds = np.zeros(W, dtype=np.uint32)
+    ids = np.nonzero((flags & 3) == 3)[0]
+    np.bitwise_or.at(bound_seeds, ids >> 5, np.uint32(1) << (ids & 31).astype(np.uint32))
+    d_bound = ctx.to_device(bound_seeds)
+    cases = (("closure_holders", 0, d_seed, nseed), ("closure_deps", 1, d_seed, nseed),
+             ("closure_holders_of_bound", 0, d_bound, len(ids)), ("closure_deps_of_bound", 1, d_bound, len(ids)))
+    for name, direction, d_s, ns in cases:
+        ctx.dep_closure_dev(d_in.ptr, d_s.ptr, d_clo.ptr, direction)
         ctx.sync()
         t0 = time.perf_counter()
         for _ in range(5):
-            edges, levels = ctx.dep_closure_dev(d_in.ptr, d_seed.ptr, d_clo.ptr, direction)
+            edges, levels = ctx.dep_closure_dev(d_in.ptr, d_s.ptr, d_clo.ptr, direction)
         ctx.sync()
         ms = (time.perf_counter() - t0) * 1e3 / 5
+        # B2b = row pointers + scanned adjacency entries + the bitmap once per level and side
+        alg = 4 * (V + 1) + 4 * edges + (V // 8) * (2 * levels + 2)
+        gbs = alg / (ms / 1e3) / 1e9 if ms > 0 else 0.0
         res[name] = {
-            "seeds": nseed,
+            "seeds": int(ns),
             "edges_scanned": edges,
             "levels": levels,
             "ms": ms,
             "edges_per_s": edges / (ms / 1e3) if ms > 0 else 0.0,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": int(alg), "traffic": None,
+                         "note": "wall time of the whole call (launches, level look-ups) over algorithmic bytes"},
         }
+    d_bound.free()
     for b in (d_in, d_seed, d_out, d_ref, d_clo):
         b.free()
     if with_cpu:

@@ -67,7 +67,8 @@ struct mcx_ctx {
     uint32_t n_hub[2] = {0, 0};    /* modules with a long adjacency list, per closure direction */
     uint32_t hub_cap = 0;
     uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */
-    uint32_t bfs_depth[2] = {0, 0}; /* levels of the last closure per direction (0: none yet) */
+    uint32_t bfs_depth[2] = {0, 0}; /* per-level launches the last closure needed per direction behind its
+                                       one-workgroup part (0: none, or no search yet) */
 
     /* holder levels of the graph (fleet pipeline): level 0 = modules nobody
      * needs, level k = modules whose holders all sit in levels < k.  lvl_order

@@ -27,7 +27,7 @@
 #define K2_EDGES 4096u
 #define K2B_BLOCKS 1024u  /* grid of one BFS level; strides over the frontier */
 #define K2B_BATCH 16u     /* most levels enqueued between two looks at the queue sizes */
-#define K2B_MAX_LEVELS 4096u
+#define K2B_MAX_LEVELS 64u   /* window of per-level counters, reused by deeper searches */
 
 /* ------------------------------------------------------------------------- */
 /* K2a: one block = one row block of the reverse CSR.                         */
@@ -562,8 +562,194 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
         atomicAdd(st.edges, scanned);
 }
 
-/* words of BFS state cleared per call: the per-level counters and the edge count */
-#define K2B_STATE_WORDS (2u * (K2B_MAX_LEVELS + 1u) + 2u)
+/* words of BFS state cleared per call: the per-level counters, the edge count, and what
+ * the one-workgroup kernel leaves for the host: levels it expanded, 1 if it handed over */
+#define K2B_STATE_WORDS (2u * (K2B_MAX_LEVELS + 1u) + 4u)
+#define K2B_W_EDGES (2u * (K2B_MAX_LEVELS + 1u))
+#define K2B_W_SMALL_LEVELS (K2B_W_EDGES + 2u)
+#define K2B_W_HANDOVER (K2B_W_EDGES + 3u)
+
+/*
+ * Closures of a few seeds have frontiers of a few hundred modules: a launch per level
+ * is then all boundary and round-trip latency.  One workgroup of 1024 threads runs such
+ * a search from start to end: the frontier lives in LDS (two queues of K2S_CAP
+ * entries, each entry = module, start and end of its adjacency list), levels are
+ * separated by __syncthreads(), the visited bitmap is the caller's output bitmap in
+ * global memory (atomic OR).  A level is the concatenation of its modules'
+ * adjacency lists, walked K2S_THREADS x K2S_PER entries a step; per entry the
+ * neighbour's flag byte and its own row pointers are requested together (the
+ * pointers are kept with the module if it turns out new, so the next level starts
+ * without a round trip of its own), then one atomic OR decides who found it.
+ * When a level outgrows the workgroup (more than K2S_CAP modules, or more than
+ * K2S_LEVEL_MAX adjacency entries: a hub) the frontier goes to the global queue
+ * and hub list in the form the per-level kernel expects, as its level 0.
+ */
+#define K2S_THREADS 1024u
+#define K2S_CAP 2048u
+#define K2S_PER 2u
+#define K2S_LEVEL_MAX 4096u /* two steps of the workgroup; more is faster on the whole chip */
+
+__global__ void __launch_bounds__(K2S_THREADS)
+k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+          const uint8_t *__restrict__ in_flags, uint32_t *__restrict__ out, uint32_t *__restrict__ queue0,
+          uint32_t *__restrict__ spill, k2b_state_t st)
+{
+    __shared__ uint32_t qv[2][K2S_CAP], qb[2][K2S_CAP], qe[2][K2S_CAP]; /* module, list start, list end */
+    __shared__ uint32_t pre[K2S_CAP + 1u];                               /* exclusive sums of the list lengths */
+    __shared__ uint32_t wsum[K2S_THREADS / 64u];
+    __shared__ uint32_t nnext_sh, nq_sh, nh_sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t n = st.cnt[0];
+    const uint32_t nh0 = st.cnt[1];
+    unsigned long long scanned = 0; /* thread 0 keeps the sum */
+    uint32_t levels = 0, cur = 0;
+
+    /* write the frontier held in LDS queue `c` (first `nl` entries) plus `ns` spilled modules out
+     * as level 0 of the per-level kernel: hubs to the hub list, the rest to the queue */
+    auto hand_over = [&](uint32_t c, uint32_t nl, uint32_t ns) {
+        if (tid == 0) {
+            nq_sh = 0;
+            nh_sh = 0;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < nl + ns; i += K2S_THREADS) {
+            const uint32_t v = i < nl ? qv[c][i] : spill[i - nl];
+            const bool hub = st.hubbits && ((st.hubbits[v >> 5] >> (v & 31u)) & 1u);
+            if (hub)
+                st.hubq[0][atomicAdd(&nh_sh, 1u)] = v;
+            else
+                queue0[atomicAdd(&nq_sh, 1u)] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            st.cnt[0] = nq_sh;
+            st.cnt[1] = nh_sh;
+            st.cnt[K2B_W_SMALL_LEVELS] = levels;
+            st.cnt[K2B_W_HANDOVER] = 1u;
+            if (scanned)
+                atomicAdd(st.edges, scanned);
+        }
+    };
+
+    if (nh0 != 0u || n > K2S_CAP) {
+        /* seeds with a hub among them, or too many: nothing done here, the queue and the
+         * hub list stay as the seed kernel wrote them */
+        if (tid == 0)
+            st.cnt[K2B_W_HANDOVER] = 1u;
+        return;
+    }
+    for (uint32_t i = tid; i < n; i += K2S_THREADS) {
+        const uint32_t v = queue0[i];
+        qv[0][i] = v;
+        qb[0][i] = rowptr[v];
+        qe[0][i] = rowptr[v + 1u];
+    }
+    __syncthreads();
+    while (n != 0u) {
+        /* exclusive sums of the list lengths: K2S_CAP / K2S_THREADS = 4 modules per thread */
+        uint32_t d[K2S_CAP / K2S_THREADS], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < K2S_CAP / K2S_THREADS; ++k) {
+            const uint32_t i = (K2S_CAP / K2S_THREADS) * tid + k;
+            d[k] = i < n ? qe[cur][i] - qb[cur][i] : 0u;
+            mine += d[k];
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (uint32_t s = 1; s < 64; s <<= 1) {
+            const uint32_t o = __shfl_up(incl, s, 64);
+            if (lane >= s)
+                incl += o;
+        }
+        if (lane == 63u)
+            wsum[wave] = incl;
+        if (tid == 0)
+            nnext_sh = 0;
+        __syncthreads();
+        uint32_t at = incl - mine, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < K2S_THREADS / 64u; ++k) {
+            if (k < wave)
+                at += wsum[k];
+            total += wsum[k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < K2S_CAP / K2S_THREADS; ++k) {
+            const uint32_t i = (K2S_CAP / K2S_THREADS) * tid + k;
+            if (i <= n)
+                pre[i] = at;
+            at += d[k];
+        }
+        __syncthreads();
+        if (total > K2S_LEVEL_MAX) {
+            hand_over(cur, n, 0u);
+            return;
+        }
+        ++levels;
+        scanned += total;
+        const uint32_t nxt = cur ^ 1u;
+        for (uint32_t j0 = 0; j0 < total; j0 += K2S_THREADS * K2S_PER) {
+            uint32_t u[K2S_PER], f[K2S_PER], b[K2S_PER], e[K2S_PER];
+            bool have[K2S_PER];
+#pragma unroll
+            for (uint32_t q = 0; q < K2S_PER; ++q) {
+                const uint32_t j = j0 + K2S_THREADS * q + tid;
+                have[q] = j < total;
+                uint32_t lo = 0, hi = n; /* largest i with pre[i] <= j */
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pre[mid] <= j)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                u[q] = have[q] ? col[qb[cur][lo] + (j - pre[lo])] : 0u;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < K2S_PER; ++q) {
+                f[q] = have[q] ? in_flags[u[q]] : 0u;
+                b[q] = have[q] ? rowptr[u[q]] : 0u;
+                e[q] = have[q] ? rowptr[u[q] + 1u] : 0u;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < K2S_PER; ++q) {
+                if (!(f[q] & MCX_F_LOADED))
+                    continue;
+                const uint32_t bit = 1u << (u[q] & 31u);
+                if (atomicOr(&out[u[q] >> 5], bit) & bit)
+                    continue;
+                const uint32_t at2 = atomicAdd(&nnext_sh, 1u);
+                if (at2 < K2S_CAP) {
+                    qv[nxt][at2] = u[q];
+                    qb[nxt][at2] = b[q];
+                    qe[nxt][at2] = e[q];
+                } else {
+                    spill[at2 - K2S_CAP] = u[q]; /* the current level's global queue: its content is in LDS */
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nn = nnext_sh;
+        if (nn > K2S_CAP) {
+            /* the spilled modules were written by this block: make them visible to its own reads */
+            __threadfence();
+            __syncthreads();
+            hand_over(nxt, K2S_CAP, nn - K2S_CAP);
+            return;
+        }
+        n = nn;
+        cur = nxt;
+        __syncthreads(); /* nnext_sh is reset at the top of the next level */
+    }
+    if (tid == 0) {
+        st.cnt[0] = 0u;
+        st.cnt[1] = 0u;
+        st.cnt[K2B_W_SMALL_LEVELS] = levels;
+        st.cnt[K2B_W_HANDOVER] = 0u;
+        if (scanned)
+            atomicAdd(st.edges, scanned);
+    }
+}
 
 /* ------------------------------------------------------------------------- */
 /* LOADED bitmap of mcx_dep_flags_noalloc_dev: a device array of the code      */
@@ -868,17 +1054,33 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uin
     return rc;
 }
 
-/* the queue sizes of a batch of levels and the edge count, written straight into
- * pinned host memory: one small launch instead of two device-to-host copies */
-__global__ void k2b_publish(const uint32_t *__restrict__ cnt, uint32_t nwords,
-                            const unsigned long long *__restrict__ edges, uint32_t *__restrict__ h_sizes,
-                            unsigned long long *__restrict__ h_edges)
+/* the queue sizes of a batch of levels, the edge count and the record of the one-workgroup
+ * kernel, written straight into pinned host memory: one small launch instead of
+ * device-to-host copies */
+__global__ void k2b_publish(const uint32_t *__restrict__ cnt, uint32_t first, uint32_t nwords,
+                            uint32_t *__restrict__ h_sizes, unsigned long long *__restrict__ h_edges,
+                            uint32_t *__restrict__ h_small)
 {
     const uint32_t i = threadIdx.x;
     if (i < nwords)
-        h_sizes[i] = cnt[i];
-    if (i == 0)
-        *h_edges = *edges;
+        h_sizes[i] = cnt[first + i];
+    if (i == 0) {
+        *h_edges = *(const unsigned long long *)(cnt + K2B_W_EDGES);
+        h_small[0] = cnt[K2B_W_SMALL_LEVELS];
+        h_small[1] = cnt[K2B_W_HANDOVER];
+    }
+}
+
+/* restart the window of per-level counters at level `base` (even, so that queue and hub list
+ * keep their parity): its two counters become those of level 0, the rest is cleared */
+__global__ void k2b_rewind(uint32_t *__restrict__ cnt, uint32_t base)
+{
+    __shared__ uint32_t keep[2];
+    if (threadIdx.x < 2u)
+        keep[threadIdx.x] = cnt[2u * base + threadIdx.x];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < K2B_W_EDGES; i += blockDim.x)
+        cnt[i] = i < 2u ? keep[i] : 0u;
 }
 
 int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed_bitmap, void *d_out_bitmap,
@@ -903,7 +1105,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     const uint32_t W = (V + 31) / 32;
     k2b_state_t st;
     st.cnt = ctx->d_bfs;
-    st.edges = (unsigned long long *)(ctx->d_bfs + K2B_STATE_WORDS - 2u); /* 8-byte aligned */
+    st.edges = (unsigned long long *)(ctx->d_bfs + K2B_W_EDGES); /* 8-byte aligned */
     st.hubq[0] = ctx->d_bfs + K2B_STATE_WORDS;
     st.hubq[1] = st.hubq[0] + ctx->hub_cap;
     st.hubbits = ctx->n_hub[direction] ? st.hubq[1] + ctx->hub_cap + (size_t)direction * W : nullptr;
@@ -911,51 +1113,71 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     k2b_seed<<<(W + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
         (const uint32_t *)d_seed_bitmap, (const uint8_t *)d_in_flags, V, (uint32_t *)d_out_bitmap,
         ctx->d_queue[0], st);
-    /* levels are enqueued a batch at a time; a level whose frontier is empty
-     * returns at once (1.7 us), and the queue sizes of a batch tell where the search
-     * ended; looking costs a stream synchronisation (25 us).  Searches over one graph
-     * tend to be equally deep, so a batch is as long as the last search in this
-     * direction was, plus two: a shallow search does not pay for a dozen empty levels
-     * and a deep one looks once.  A path visits each vertex once, so V levels always
-     * suffice. */
-    const uint32_t hint = ctx->bfs_depth[direction];
-    const uint32_t batch = hint ? (hint + 2u < 4u ? 4u : (hint + 2u > K2B_BATCH ? K2B_BATCH : hint + 2u)) : 8u;
-    uint32_t lv = 0;
     uint32_t *sizes = ctx->h_pinned;                                  /* 2 * K2B_BATCH words */
     unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 2 * K2B_BATCH);
+    uint32_t *h_small = ctx->h_pinned + 2 * K2B_BATCH + 2;            /* levels, handed over */
     uint32_t *d_sizes = nullptr; /* the same pinned memory as the device addresses it */
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&d_sizes, sizes, 0));
     unsigned long long *d_edges = (unsigned long long *)(d_sizes + 2 * K2B_BATCH);
-    bool done = false;
-    while (!done) {
-        if (lv + batch > K2B_MAX_LEVELS) {
-            ctx->err = "closure deeper than 4096 levels";
-            return MCX_E_TOO_LARGE;
-        }
-        for (uint32_t b = 0; b < batch; ++b) {
-            const uint32_t level = lv + b;
-            k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags,
-                                                                  ctx->d_queue[level & 1u],
-                                                                  (uint32_t *)d_out_bitmap,
-                                                                  ctx->d_queue[(level + 1u) & 1u], st, level);
-        }
-        HIPCHK(ctx, hipGetLastError());
-        k2b_publish<<<1, 64, 0, ctx->stream>>>(&st.cnt[2u * lv], 2u * batch, st.edges, d_sizes, d_edges);
+    uint32_t *d_small = d_sizes + 2 * K2B_BATCH + 2;
+    /* first the whole search in one workgroup, as far as it stays small (most closures of a
+     * few modules end there: one launch, one look) */
+    k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags, (uint32_t *)d_out_bitmap,
+                                                  ctx->d_queue[0], ctx->d_queue[1], st);
+    /* a search that handed over last time in this direction will most likely do so again:
+     * its first batch of levels is then enqueued without a look in between */
+    const bool expect_handover = ctx->bfs_depth[direction] != 0u;
+    if (!expect_handover) {
+        k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 0u, 2u, d_sizes, d_edges, d_small);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t b = 0; b < batch; ++b) {
-            if (sizes[2u * b] == 0u && sizes[2u * b + 1u] == 0u) {
-                done = true;
-                break;
+    }
+    uint32_t lv = 0;
+    if (expect_handover || h_small[1] != 0u) {
+        /* handed over: a launch per level from here.  Levels are enqueued a batch at a time; a
+         * level whose frontier is empty returns at once (1.7 us), and the queue sizes of a batch
+         * tell where the search ended; looking costs a stream synchronisation.  Searches over
+         * one graph tend to be equally deep, so a batch is as long as the last search in this
+         * direction was, plus two (even, so that the counter window can be restarted at a batch
+         * boundary): a shallow search does not pay for a dozen empty levels and a deep one looks
+         * once.  The window of K2B_MAX_LEVELS per-level counters is reused as often as needed. */
+        const uint32_t hint = ctx->bfs_depth[direction];
+        uint32_t batch = hint ? (hint + 2u < 4u ? 4u : (hint + 2u > K2B_BATCH ? K2B_BATCH : hint + 2u)) : 8u;
+        batch = (batch + 1u) & ~1u;
+        uint32_t base = 0; /* level of the counter window the next batch starts at */
+        bool done = false;
+        while (!done) {
+            if (base + batch + 1u > K2B_MAX_LEVELS) {
+                k2b_rewind<<<1, 256, 0, ctx->stream>>>(st.cnt, base);
+                base = 0;
             }
-            ++lv;
+            for (uint32_t b = 0; b < batch; ++b) {
+                const uint32_t level = base + b;
+                k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags,
+                                                                      ctx->d_queue[level & 1u],
+                                                                      (uint32_t *)d_out_bitmap,
+                                                                      ctx->d_queue[(level + 1u) & 1u], st, level);
+            }
+            HIPCHK(ctx, hipGetLastError());
+            k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, d_sizes, d_edges, d_small);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint32_t b = 0; b < batch; ++b) {
+                if (sizes[2u * b] == 0u && sizes[2u * b + 1u] == 0u) {
+                    done = true;
+                    break;
+                }
+                ++lv;
+            }
+            base += batch;
         }
+        /* 0: the one-workgroup kernel did it all (its levels then all read as empty here) */
+        ctx->bfs_depth[direction] = h_small[1] ? (lv > K2B_BATCH ? K2B_BATCH : (lv ? lv : 1u)) : 0u;
     }
     if (edges_scanned)
         *edges_scanned = *h_edges;
     if (levels)
-        *levels = lv;
-    ctx->bfs_depth[direction] = lv ? lv : 1u;
+        *levels = h_small[0] + lv;
     return MCX_OK;
 }
 

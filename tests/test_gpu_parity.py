@@ -415,6 +415,52 @@ def test_k2_hubs(gpu_ctx, oracle_mod):
         check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
 
 
+def test_k2_deep_and_wide_searches(gpu_ctx, oracle_mod):
+    """Searches far deeper than the window of per-level counters: a single chain of 5000
+    modules (one module per level: the one-workgroup path from start to end), 3000 chains
+    side by side (a frontier too large for one workgroup: a launch per level, 120 levels,
+    the counter window restarted), and chains that fan out at their end (small levels
+    first, then a hand-over in the middle of the search)."""
+    def csr(V, edges):
+        e = np.array(sorted(edges), dtype=np.uint32).reshape(-1, 2)
+        rowptr = np.zeros(V + 1, dtype=np.uint32)
+        np.add.at(rowptr, e[:, 0].astype(np.int64) + 1, 1)
+        return np.cumsum(rowptr, dtype=np.uint64).astype(np.uint32), np.ascontiguousarray(e[:, 1])
+
+    def bitmap(V, picks):
+        bm = np.zeros((V + 31) // 32, dtype=np.uint32)
+        for v in picks:
+            bm[v >> 5] |= np.uint32(1 << (v & 31))
+        return bm
+
+    # one chain: module i needs module i + 1
+    V = 5000
+    rowptr, col = csr(V, [(i, i + 1) for i in range(V - 1)])
+    flags = np.full(V, 5, np.uint8)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, bitmap(V, [0]))        # deps direction walks it all
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, bitmap(V, [V - 1]))    # holders direction too
+    flags[2500] = 4                                                          # an unloaded module cuts it
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, bitmap(V, [0, V - 1]))
+    # 3000 chains of 120 modules side by side: chain c holds modules c, c + 3000, c + 6000, ...
+    C, Ln = 3000, 120
+    V = C * Ln
+    rowptr, col = csr(V, [(c + C * k, c + C * (k + 1)) for c in range(C) for k in range(Ln - 1)])
+    flags = np.full(V, 5, np.uint8)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, bitmap(V, range(C)))
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, bitmap(V, range(V - C, V)))
+    # ten chains of 80 whose last module needs 600 leaves each: small, small, ..., then wide
+    edges, V = [], 0
+    for c in range(10):
+        base = V
+        edges += [(base + k, base + k + 1) for k in range(79)]
+        edges += [(base + 79, base + 80 + j) for j in range(600)]
+        V += 80 + 600
+    rowptr, col = csr(V, edges)
+    flags = np.full(V, 5, np.uint8)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, bitmap(V, [c * 680 for c in range(10)]))
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, bitmap(V, [c * 680 + 100 for c in range(10)]))
+
+
 def test_k2_full_size(gpu_ctx, oracle_mod):
     """configs[2]: 1M modules, ~10M edges.  The oracle still finishes in seconds, so
     this is a direct comparison plus the closure properties (idempotence, seeds
