@@ -107,6 +107,52 @@ def alias_match(arena, a_off, S, s_off, normalize_dash=False, i0=0, i1=None, use
     return first[i0:i1], count[i0:i1]
 
 
+def alias_match_sample(arena, a_off, S, s_off, picks, normalize_dash=False, threads=None):
+    """(first_idx, count) of the strings `picks` by glibc fnmatch, the strings dealt over
+    `threads` threads (the C loop runs without the interpreter lock)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    picks = [int(i) for i in picks]
+    a_off = np.ascontiguousarray(a_off, dtype=np.uint32)
+    s_off = np.ascontiguousarray(s_off, dtype=np.uint32)
+    P = len(a_off) - 1
+    raw = np.ascontiguousarray(S, dtype=np.uint8)
+    parts = [raw[s_off[i]:s_off[i + 1]] for i in picks]
+    SS = _c(np.concatenate(parts) if parts else np.zeros(0, np.uint8), np.uint8)
+    ss_off = np.zeros(len(picks) + 1, dtype=np.uint32)
+    ss_off[1:] = np.cumsum([len(x) for x in parts], dtype=np.uint64)
+    n = len(picks)
+    first = np.full(max(n, 1), NO_MATCH, dtype=np.uint32)
+    count = np.zeros(max(n, 1), dtype=np.uint32)
+    A = _c(arena, np.uint8)
+    threads = threads or max(1, min(16, len(os.sched_getaffinity(0))))
+    cut = [n * t // threads for t in range(threads + 1)]
+    lib = oracle()
+
+    def work(t):
+        if cut[t + 1] > cut[t]:
+            lib.orc_alias_match(_p(A), _p(a_off), P, _p(SS), _p(ss_off), cut[t], cut[t + 1], int(normalize_dash),
+                                _p(first), _p(count))
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(work, range(threads)))
+    return first[:n], count[:n]
+
+
+def hw_alias_flags(arena, a_off, a_mod, n_modules):
+    """hw[m] = 1 iff module m owns an alias line that starts (after blanks) with one of the
+    six bus tags of reference desktop/ui.py:1540, decided pattern by pattern on the host"""
+    a_off = np.ascontiguousarray(a_off, dtype=np.uint32)
+    raw = np.ascontiguousarray(arena, dtype=np.uint8).tobytes()
+    hw = np.zeros(n_modules, dtype=np.uint8)
+    lib = oracle()
+    for j in range(len(a_off) - 1):
+        m = int(a_mod[j])
+        if m < n_modules and not hw[m] and lib.orc_has_hw_alias(raw[a_off[j]:a_off[j + 1]]):
+            hw[m] = 1
+    return hw
+
+
 def alias_match_list(arena, a_off, S, s_off, K=0, normalize_dash=False):
     """(list_off, list_idx): every matching table position per string in table order, first K if K > 0"""
     a_off = np.ascontiguousarray(a_off, dtype=np.uint32)

@@ -26,9 +26,17 @@ def make_fleet(seed, P, H, mean_dev, max_extra, mean_deg=4):
 
 
 def oracle_fleet(oracle_mod, ctx, f, use_twin=False):
-    first, _ = oracle_mod.alias_match(f["A"], f["a_off"], f["S"], f["s_off"], use_twin=use_twin)
+    first, count = oracle_mod.alias_match(f["A"], f["a_off"], f["S"], f["s_off"], use_twin=use_twin)
+    if use_twin:
+        # the twin's answers are the expectation: 1000 of them spread over the fleet pinned by glibc
+        N = len(f["s_off"]) - 1
+        picks = sorted(set(np.random.default_rng(N).choice(N, size=min(N, 1000), replace=False).tolist()))
+        g_first, g_count = oracle_mod.alias_match_sample(f["A"], f["a_off"], f["S"], f["s_off"], picks)
+        assert np.array_equal(first[picks], g_first) and np.array_equal(count[picks], g_count)
     driver = np.where(first != NO_MATCH, f["a_mod"][np.minimum(first, len(f["a_mod"]) - 1)], NO_MATCH)
-    hw = ctx.alias_hw_flags(f["V"])  # checked on its own against the reference's rule in test_k1_hw_flags
+    # the hardware-alias stage decided on the host from the table's text (the six tags of
+    # reference desktop/ui.py:1540), not taken from the library under test
+    hw = oracle_mod.hw_alias_flags(f["A"], f["a_off"], f["a_mod"], f["V"])
     return oracle_mod.fleet_roots(f["rowptr"], f["col"], driver.astype(np.uint32), f["dev_off"], f["extra_off"],
                                   f["extra_ids"], f["safe"], hw)
 
