@@ -256,6 +256,39 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
                         void *d_root_off, void *d_root_ids, uint64_t cap,
                         uint64_t *total_out);
 
+/*
+ * The same lists with the reference's own notion of a used driver: the driver
+ * BOUND to each listed device (desktop/ui.py:1358-1359 collects the `driver`
+ * field of every record, the base name of the sysfs driver link,
+ * montecarlo/libmontecarlo.c:400-424), compared byte for byte with the module
+ * names (ui.py:1567: no '-' / '_' folding, so a device bound to "virtio-pci" does
+ * not make module virtio_pci a used driver).  bound_mod[i] = id of the module
+ * named exactly like device i's driver, MCX_NO_MATCH for an unbound device or a
+ * driver name that is no module name (mcx_driver_modules builds that map).  Per host:
+ *   used   = { bound_mod[i] }
+ *   loaded = used + { a_mod[first_idx[i]] } + extras, closed under "needs"
+ * and the rest as above.  A device whose modalias resolves to a module that did not
+ * bind - the case the reference's brute-force loop looks for, ui.py:1854-1920 -
+ * leaves that module loaded and unused: it is listed if nothing holds it.
+ */
+int mcx_fleet_roots_bound(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N,
+                          const uint32_t *dev_off, uint32_t H,
+                          const uint32_t *extra_off, const uint32_t *extra_ids,
+                          const uint8_t *safe_name, const uint32_t *bound_mod,
+                          uint32_t *root_off, uint32_t *root_ids, uint64_t cap,
+                          uint64_t *total_out);
+int mcx_fleet_roots_bound_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N,
+                              const void *d_dev_off, uint32_t H,
+                              const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                              const void *d_safe_name, const void *d_bound_mod,
+                              void *d_root_off, void *d_root_ids, uint64_t cap,
+                              uint64_t *total_out);
+/* drv_mod[d] = id of the module whose name equals driver name d byte for byte, else
+ * MCX_NO_MATCH; names packed like patterns.  Host only, no context needed. */
+int mcx_driver_modules(const char *drv_arena, const uint32_t *drv_off, uint32_t D,
+                       const char *mod_names, const uint32_t *mod_off, uint32_t V,
+                       uint32_t *drv_mod);
+
 /* ---- fleet inventory: which devices a host would list --------------------- */
 
 /*
@@ -355,7 +388,7 @@ int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, 
  * The whole of configs "inventory -> module lists" in one call, device buffers:
  * mcx_device_filter_dev (verdicts are left in d_verdict), the packing of the
  * listed devices' strings, and mcx_fleet_roots_dev over them; arguments as
- * in those three.  Allocates and frees the packed strings itself.
+ * in those three.  The packed strings live in a buffer the context keeps.
  */
 int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
                                   uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
@@ -363,6 +396,17 @@ int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d
                                   const void *d_extra_off, const void *d_extra_ids, uint32_t X,
                                   const void *d_safe_name, void *d_verdict,
                                   void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out);
+
+/* The same with the used drivers taken from the records' bound drivers
+ * (mcx_fleet_roots_bound_dev): d_drv_mod holds D module ids, the output of
+ * mcx_driver_modules for the driver-name table, on the device. */
+int mcx_fleet_inventory_roots_bound_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
+                                        uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                                        const void *d_drv_mod,
+                                        const void *d_dev_off, uint32_t H, uint32_t max_per_host,
+                                        const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                                        const void *d_safe_name, void *d_verdict,
+                                        void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out);
 
 /* ---- the library's name tables as data ------------------------------------ */
 

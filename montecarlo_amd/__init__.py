@@ -23,6 +23,7 @@ from .binding import (  # noqa: F401
     CLOSURE_DEPS,
     TABLE_NORMALIZE_DASH,
     safe_module_names,
+    driver_modules,
     pack_strings,
     DEV_REC,
     tables_load,

@@ -165,6 +165,23 @@ def load_library():
             [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp,
              ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
         ),
+        "mcx_fleet_roots_bound": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64,
+             ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_fleet_roots_bound_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp,
+             ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_fleet_inventory_roots_bound_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32,
+             ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_uint64,
+             ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_driver_modules": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -403,6 +420,26 @@ class Context:
         self._check(rc, "mcx_fleet_roots")
         return root_off, ids[: total.value]
 
+    def fleet_roots_bound(self, S, s_off, dev_off, extra_off, extra_ids, safe_name, bound_mod, cap=None):
+        """mcx_fleet_roots_bound: used drivers = bound_mod[i] (module named like device i's bound driver)"""
+        S, s_off = _as(S, np.uint8), _as(s_off, np.uint32)
+        dev_off, extra_off = _as(dev_off, np.uint32), _as(extra_off, np.uint32)
+        extra_ids, safe_name, bound_mod = _as(extra_ids, np.uint32), _as(safe_name, np.uint8), _as(bound_mod, np.uint32)
+        N, H = len(s_off) - 1, len(dev_off) - 1
+        if len(extra_off) != H + 1 or len(safe_name) != self.V or len(bound_mod) != N:
+            raise ValueError("extra_off needs H+1 entries, safe_name V entries, bound_mod N entries")
+        root_off = np.zeros(H + 1, dtype=np.uint32)
+        total = ctypes.c_uint64()
+        ids = np.zeros(int(cap) if cap else 1, dtype=np.uint32)
+        args = (self.h, _ptr(S), _ptr(s_off), N, _ptr(dev_off), H, _ptr(extra_off), _ptr(extra_ids),
+                _ptr(safe_name), _ptr(bound_mod), _ptr(root_off))
+        rc = self.lib.mcx_fleet_roots_bound(*args, _ptr(ids), int(cap) if cap else 0, ctypes.byref(total))
+        if rc == -6 and cap is None and total.value < 2**32:
+            ids = np.zeros(total.value, dtype=np.uint32)
+            rc = self.lib.mcx_fleet_roots_bound(*args, _ptr(ids), total.value, ctypes.byref(total))
+        self._check(rc, "mcx_fleet_roots_bound")
+        return root_off, ids[: total.value]
+
     def fleet_roots_dev(self, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe, d_root_off,
                         d_root_ids, cap, size_only=False):
         """returns the total; with size_only a too-small root_ids is not an error"""
@@ -489,6 +526,32 @@ class Context:
         if not (size_only and rc == -6 and cap < total.value < 2**32):
             self._check(rc, "mcx_fleet_inventory_roots_dev")
         return total.value
+
+    def fleet_inventory_roots_bound_dev(self, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, d_drv_mod, d_dev_off,
+                                        H, max_per_host, d_extra_off, d_extra_ids, X, d_safe, d_verdict, d_root_off,
+                                        d_root_ids, cap, size_only=False):
+        """the same with the used drivers taken from the records' bound drivers (d_drv_mod: D module ids)"""
+        total = ctypes.c_uint64()
+        rc = self.lib.mcx_fleet_inventory_roots_bound_dev(self.h, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D,
+                                                          d_drv_mod, d_dev_off, H, int(max_per_host), d_extra_off,
+                                                          d_extra_ids, X, d_safe, d_verdict, d_root_off, d_root_ids,
+                                                          cap, ctypes.byref(total))
+        if not (size_only and rc == -6 and cap < total.value < 2**32):
+            self._check(rc, "mcx_fleet_inventory_roots_bound_dev")
+        return total.value
+
+
+def driver_modules(driver_names, module_names):
+    """drv_mod[d] = id of the module named exactly like driver d (no '-' / '_' folding), NO_MATCH if none"""
+    lib = load_library()
+    d_arena, d_off = pack_strings([n.encode() if isinstance(n, str) else n for n in driver_names])
+    m_arena, m_off = pack_strings([n.encode() if isinstance(n, str) else n for n in module_names])
+    out = np.zeros(max(len(driver_names), 1), dtype=np.uint32)
+    rc = lib.mcx_driver_modules(_ptr(d_arena) if len(d_arena) else None, _ptr(d_off), len(driver_names),
+                                _ptr(m_arena) if len(m_arena) else None, _ptr(m_off), len(module_names), _ptr(out))
+    if rc != 0:
+        raise McxError(rc, "mcx_driver_modules")
+    return out[: len(driver_names)]
 
 
 def safe_module_names(names):

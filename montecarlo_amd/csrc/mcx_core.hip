@@ -138,6 +138,7 @@ void mcx_ctx_destroy(mcx_ctx *ctx)
     mcx_free_table(ctx);
     mcx_free_graph(ctx);
     (void)hipFree(ctx->d_fleet);
+    (void)hipFree(ctx->d_inv);
     (void)hipFree(ctx->d_io);
     if (ctx->h_io)
         (void)hipHostFree(ctx->h_io);

@@ -20,6 +20,8 @@
  */
 #include <string.h>
 
+#include <unordered_map>
+
 #include "mcx_internal.h"
 #include "mcx_scan.h"
 #include "tables.h"
@@ -357,12 +359,24 @@ int mcx_fleet_compact_dev(mcx_ctx *ctx, const void *d_verdict, const void *d_S, 
     return MCX_OK;
 }
 
-int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
-                                  uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
-                                  const void *d_dev_off, uint32_t H, uint32_t max_per_host,
-                                  const void *d_extra_off, const void *d_extra_ids, uint32_t X,
-                                  const void *d_safe_name, void *d_verdict, void *d_root_off, void *d_root_ids,
-                                  uint64_t cap, uint64_t *total_out)
+/* bound[k] = module named like the driver of the k-th listed device (drv_mod by driver number) */
+__global__ void __launch_bounds__(256)
+dv_bound_of_kept(const mcx_dev_rec_t *__restrict__ rec, const uint32_t *__restrict__ src, uint32_t K,
+                 const uint32_t *__restrict__ drv_mod, uint32_t D, uint32_t *__restrict__ bound)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K)
+        return;
+    const uint32_t d = rec[src[k]].driver;
+    bound[k] = d < D ? drv_mod[d] : MCX_NO_MATCH;
+}
+
+/* d_drv_mod == nullptr: used drivers from the alias match; otherwise from the records' bound drivers */
+static int inventory_roots(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off, uint32_t N,
+                           const void *d_drv_arena, const void *d_drv_off, uint32_t D, const void *d_drv_mod,
+                           const void *d_dev_off, uint32_t H, uint32_t max_per_host, const void *d_extra_off,
+                           const void *d_extra_ids, uint32_t X, const void *d_safe_name, void *d_verdict,
+                           void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out)
 {
     if (!ctx || !d_s_off || !d_dev_off || !d_root_off || !total_out || (N && !d_verdict))
         return MCX_E_BAD_ARG;
@@ -371,29 +385,99 @@ int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d
     *total_out = 0;
     if (mcx_set_device(ctx))
         return MCX_E_HIP;
-    /* the listed devices' strings live in a buffer of this call: the stages
-     * share the context's scratch, which may move when it grows */
-    uint32_t s_bytes = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&s_bytes, (const uint32_t *)d_s_off + N, 4, hipMemcpyDeviceToHost, ctx->stream));
+    /* the listed devices' strings live in a buffer of their own, kept by the context and
+     * grown on demand: the stages share the context's scratch, which may move when it grows */
+    uint32_t *h_bytes = ctx->h_pinned;
+    HIPCHK(ctx, hipMemcpyAsync(h_bytes, (const uint32_t *)d_s_off + N, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t s_bytes = *h_bytes;
     const size_t o_soff = up256(s_bytes ? s_bytes : 1), o_kept = o_soff + up256(4 * ((size_t)N + 1));
-    char *tmp = nullptr;
-    if (hipMalloc((void **)&tmp, o_kept + up256(4 * ((size_t)H + 1))) != hipSuccess) {
-        ctx->err = "hipMalloc of the packed strings failed";
-        return MCX_E_NOMEM;
+    const size_t o_src = o_kept + up256(4 * ((size_t)H + 1)), o_bound = o_src + up256(4 * (size_t)(N ? N : 1));
+    const size_t need = o_bound + up256(4 * (size_t)(N ? N : 1));
+    if (ctx->inv_bytes < need) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_inv);
+        ctx->d_inv = nullptr;
+        ctx->inv_bytes = 0;
+        if (hipMalloc(&ctx->d_inv, need) != hipSuccess) {
+            ctx->err = "hipMalloc of the packed strings failed";
+            return MCX_E_NOMEM;
+        }
+        ctx->inv_bytes = need;
     }
+    char *tmp = (char *)ctx->d_inv;
     uint64_t kept = 0;
     int rc = mcx_device_filter_dev(ctx, d_rec, N, d_drv_arena, d_drv_off, D, d_dev_off, H, max_per_host, d_verdict,
                                    tmp + o_kept, &kept);
     if (rc == MCX_OK)
         rc = mcx_fleet_compact_dev(ctx, d_verdict, d_S, d_s_off, N, d_dev_off, H, tmp + o_kept, (uint32_t)kept, tmp,
-                                   tmp + o_soff, nullptr, nullptr);
-    if (rc == MCX_OK)
-        rc = mcx_fleet_roots_dev(ctx, tmp, tmp + o_soff, (uint32_t)kept, tmp + o_kept, H, d_extra_off, d_extra_ids, X,
-                                 d_safe_name, d_root_off, d_root_ids, cap, total_out);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    return rc;
+                                   tmp + o_soff, d_drv_mod ? tmp + o_src : nullptr, nullptr);
+    if (rc != MCX_OK)
+        return rc;
+    if (!d_drv_mod)
+        return mcx_fleet_roots_dev(ctx, tmp, tmp + o_soff, (uint32_t)kept, tmp + o_kept, H, d_extra_off, d_extra_ids,
+                                   X, d_safe_name, d_root_off, d_root_ids, cap, total_out);
+    if (kept)
+        dv_bound_of_kept<<<((uint32_t)kept + 255u) / 256u, 256, 0, ctx->stream>>>(
+            (const mcx_dev_rec_t *)d_rec, (const uint32_t *)(tmp + o_src), (uint32_t)kept,
+            (const uint32_t *)d_drv_mod, D, (uint32_t *)(tmp + o_bound));
+    HIPCHK(ctx, hipGetLastError());
+    return mcx_fleet_roots_bound_dev(ctx, tmp, tmp + o_soff, (uint32_t)kept, tmp + o_kept, H, d_extra_off,
+                                     d_extra_ids, X, d_safe_name, tmp + o_bound, d_root_off, d_root_ids, cap,
+                                     total_out);
+}
+
+int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
+                                  uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                                  const void *d_dev_off, uint32_t H, uint32_t max_per_host,
+                                  const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                                  const void *d_safe_name, void *d_verdict, void *d_root_off, void *d_root_ids,
+                                  uint64_t cap, uint64_t *total_out)
+{
+    return inventory_roots(ctx, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, nullptr, d_dev_off, H,
+                           max_per_host, d_extra_off, d_extra_ids, X, d_safe_name, d_verdict, d_root_off, d_root_ids,
+                           cap, total_out);
+}
+
+int mcx_fleet_inventory_roots_bound_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
+                                        uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                                        const void *d_drv_mod, const void *d_dev_off, uint32_t H,
+                                        uint32_t max_per_host, const void *d_extra_off, const void *d_extra_ids,
+                                        uint32_t X, const void *d_safe_name, void *d_verdict, void *d_root_off,
+                                        void *d_root_ids, uint64_t cap, uint64_t *total_out)
+{
+    if (D && !d_drv_mod)
+        return MCX_E_BAD_ARG;
+    /* D == 0: every device is unbound; any non-null pointer selects the mode, nothing is read through it */
+    return inventory_roots(ctx, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, d_drv_mod ? d_drv_mod : d_rec,
+                           d_dev_off, H, max_per_host, d_extra_off, d_extra_ids, X, d_safe_name, d_verdict,
+                           d_root_off, d_root_ids, cap, total_out);
+}
+
+/* host: drv_mod[d] = id of the module whose name is byte for byte the d-th driver name
+ * (the comparison of reference desktop/ui.py:1567: no '-' / '_' folding), MCX_NO_MATCH if none */
+int mcx_driver_modules(const char *drv_arena, const uint32_t *drv_off, uint32_t D, const char *mod_names,
+                       const uint32_t *mod_off, uint32_t V, uint32_t *drv_mod)
+{
+    if ((D && (!drv_off || !drv_mod)) || (V && !mod_off))
+        return MCX_E_BAD_ARG;
+    for (uint32_t d = 0; d < D; ++d)
+        if (drv_off[d + 1] < drv_off[d])
+            return MCX_E_BAD_ARG;
+    for (uint32_t v = 0; v < V; ++v)
+        if (mod_off[v + 1] < mod_off[v])
+            return MCX_E_BAD_ARG;
+    if ((D && drv_off[D] && !drv_arena) || (V && mod_off[V] && !mod_names))
+        return MCX_E_BAD_ARG;
+    std::unordered_map<std::string, uint32_t> by_name;
+    by_name.reserve(V);
+    for (uint32_t v = 0; v < V; ++v) /* the first module of a name keeps it */
+        by_name.emplace(std::string(mod_names + mod_off[v], mod_off[v + 1] - mod_off[v]), v);
+    for (uint32_t d = 0; d < D; ++d) {
+        auto it = by_name.find(std::string(drv_arena + drv_off[d], drv_off[d + 1] - drv_off[d]));
+        drv_mod[d] = it == by_name.end() ? MCX_NO_MATCH : it->second;
+    }
+    return MCX_OK;
 }
 
 int mcx_device_filter(mcx_ctx *ctx, const mcx_dev_rec_t *rec, uint32_t N, const char *drv_arena,

@@ -49,8 +49,9 @@ __device__ __forceinline__ void fl_set(uint32_t *M, uint32_t HW, uint32_t m, uin
  * thread searches there.
  */
 __global__ void __launch_bounds__(FL_THREADS)
-fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restrict__ a_mod, uint32_t N,
-                const uint32_t *__restrict__ dev_off, uint32_t H, uint32_t V, uint32_t HW, uint32_t *U)
+fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restrict__ a_mod,
+                const uint32_t *__restrict__ bound_mod, uint32_t N,
+                const uint32_t *__restrict__ dev_off, uint32_t H, uint32_t V, uint32_t HW, uint32_t *U, uint32_t *L)
 {
     __shared__ uint32_t run[FL_THREADS + 1]; /* dev_off[h0 .. h0 + FL_THREADS] */
     const uint32_t i0 = blockIdx.x * FL_THREADS;
@@ -61,11 +62,12 @@ fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restri
     __syncthreads();
     if (i >= N)
         return;
+    /* the module the device's modalias resolves to, and - when the caller says which
+     * driver is bound to the device - the module of that name */
     const uint32_t j = first_idx[i];
-    if (j == MCX_NO_MATCH)
-        return;
-    const uint32_t m = a_mod[j];
-    if (m >= V)
+    const uint32_t m = j == MCX_NO_MATCH ? MCX_NO_MATCH : a_mod[j];
+    const uint32_t b = bound_mod ? bound_mod[i] : MCX_NO_MATCH;
+    if (m >= V && b >= V)
         return;
     /* largest k with run[k] <= i; beyond the copied run (256 hosts without a
      * device in a row) the search goes back to the whole array */
@@ -83,7 +85,14 @@ fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restri
         }
         h = h0 + lo;
     }
-    fl_set(U, HW, m, h);
+    if (!bound_mod) {
+        fl_set(U, HW, m, h); /* used = resolved */
+    } else {
+        if (m < V)
+            fl_set(L, HW, m, h); /* resolved: loaded, like a module loaded by hand */
+        if (b < V)
+            fl_set(U, HW, b, h); /* used = bound */
+    }
 }
 
 /* one thread per entry of the hosts' extra-module lists: L[module][host] */
@@ -225,10 +234,11 @@ fl_seg_prefix(uint32_t *__restrict__ seg_cnt, uint32_t H, uint32_t *__restrict__
 
 extern "C" {
 
-int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
-                        uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
-                        const void *d_safe_name, void *d_root_off, void *d_root_ids, uint64_t cap,
-                        uint64_t *total_out)
+/* d_bound_mod == nullptr: used = the modules the modaliases resolve to; otherwise used = d_bound_mod[i] */
+static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
+                               uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                               const void *d_safe_name, const void *d_bound_mod, void *d_root_off, void *d_root_ids,
+                               uint64_t cap, uint64_t *total_out)
 {
     if (!ctx || !d_s_off || !d_dev_off || !d_extra_off || !d_root_off || !total_out || (X && !d_extra_ids) ||
         (cap && !d_root_ids))
@@ -276,7 +286,7 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
         if ((rc = mcx_alias_match_dev(ctx, d_S, d_s_off, N, d_first, d_count)) != MCX_OK)
             return rc;
         fl_scatter_used<<<(N + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
-            d_first, ctx->d_amod, N, (const uint32_t *)d_dev_off, H, V, HW, U);
+            d_first, ctx->d_amod, (const uint32_t *)d_bound_mod, N, (const uint32_t *)d_dev_off, H, V, HW, U, L);
     }
     if (X)
         fl_scatter_extra<<<(X + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
@@ -319,11 +329,32 @@ int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
     return MCX_OK;
 }
 
-int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
-                    uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids, const uint8_t *safe_name,
-                    uint32_t *root_off, uint32_t *root_ids, uint64_t cap, uint64_t *total_out)
+int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
+                        uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                        const void *d_safe_name, void *d_root_off, void *d_root_ids, uint64_t cap,
+                        uint64_t *total_out)
 {
-    if (!ctx || !s_off || !dev_off || !extra_off || !root_off || !total_out)
+    return fleet_roots_enqueue(ctx, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe_name, nullptr,
+                               d_root_off, d_root_ids, cap, total_out);
+}
+
+int mcx_fleet_roots_bound_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
+                              uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                              const void *d_safe_name, const void *d_bound_mod, void *d_root_off, void *d_root_ids,
+                              uint64_t cap, uint64_t *total_out)
+{
+    if (N && !d_bound_mod)
+        return MCX_E_BAD_ARG;
+    return fleet_roots_enqueue(ctx, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe_name,
+                               N ? d_bound_mod : nullptr, d_root_off, d_root_ids, cap, total_out);
+}
+
+static int fleet_roots_host(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
+                            uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids,
+                            const uint8_t *safe_name, const uint32_t *bound_mod, bool with_bound, uint32_t *root_off,
+                            uint32_t *root_ids, uint64_t cap, uint64_t *total_out)
+{
+    if (!ctx || !s_off || !dev_off || !extra_off || !root_off || !total_out || (with_bound && N && !bound_mod))
         return MCX_E_BAD_ARG;
     if (!ctx->table_loaded || !ctx->graph_loaded)
         return MCX_E_NOT_LOADED;
@@ -353,7 +384,8 @@ int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
     const size_t o_xoff = o_dev + up256(4 * ((size_t)H + 1)), o_xid = o_xoff + up256(4 * ((size_t)H + 1));
     const size_t o_safe = o_xid + up256(4 * (size_t)(X ? X : 1)), o_roff = o_safe + up256(V ? V : 1);
     const size_t o_rid = o_roff + up256(4 * ((size_t)H + 1));
-    const size_t bytes = o_rid + up256(4 * (size_t)(cap ? cap : 1));
+    const size_t o_bound = o_rid + up256(4 * (size_t)(cap ? cap : 1));
+    const size_t bytes = o_bound + up256(4 * (size_t)(N ? N : 1));
     char *d = nullptr;
     if (hipMalloc((void **)&d, bytes) != hipSuccess) {
         ctx->err = "hipMalloc of the staging buffers failed";
@@ -372,14 +404,17 @@ int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
         e = hipMemcpyAsync(d + o_xid, extra_ids, 4 * (size_t)X, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && V)
         e = hipMemcpyAsync(d + o_safe, safe_name, V, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && with_bound && N)
+        e = hipMemcpyAsync(d + o_bound, bound_mod, 4 * (size_t)N, hipMemcpyHostToDevice, ctx->stream);
     int rc = MCX_OK;
     if (e != hipSuccess) {
         ctx->err = std::string("copy in: ") + hipGetErrorString(e);
         rc = MCX_E_HIP;
     }
     if (rc == MCX_OK)
-        rc = mcx_fleet_roots_dev(ctx, d, d + o_soff, N, d + o_dev, H, d + o_xoff, d + o_xid, X, d + o_safe,
-                                 d + o_roff, cap ? d + o_rid : nullptr, cap, total_out);
+        rc = fleet_roots_enqueue(ctx, d, d + o_soff, N, d + o_dev, H, d + o_xoff, d + o_xid, X, d + o_safe,
+                                 with_bound && N ? d + o_bound : nullptr, d + o_roff, cap ? d + o_rid : nullptr, cap,
+                                 total_out);
     /* the offsets are valid even when root_ids was too small: a caller may
      * size the list from them and call again */
     if (rc == MCX_OK || (rc == MCX_E_TOO_LARGE && *total_out <= 0xFFFFFFFFull && *total_out > cap)) {
@@ -396,6 +431,23 @@ int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
+}
+
+int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
+                    uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids, const uint8_t *safe_name,
+                    uint32_t *root_off, uint32_t *root_ids, uint64_t cap, uint64_t *total_out)
+{
+    return fleet_roots_host(ctx, S, s_off, N, dev_off, H, extra_off, extra_ids, safe_name, nullptr, false, root_off,
+                            root_ids, cap, total_out);
+}
+
+int mcx_fleet_roots_bound(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
+                          uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids, const uint8_t *safe_name,
+                          const uint32_t *bound_mod, uint32_t *root_off, uint32_t *root_ids, uint64_t cap,
+                          uint64_t *total_out)
+{
+    return fleet_roots_host(ctx, S, s_off, N, dev_off, H, extra_off, extra_ids, safe_name, bound_mod, true, root_off,
+                            root_ids, cap, total_out);
 }
 
 } /* extern "C" */

@@ -83,6 +83,10 @@ struct mcx_ctx {
     void *h_io = nullptr;          /* pinned mirror of d_io for small host-buffer calls */
     size_t h_io_bytes = 0;
 
+    /* packed strings of the listed devices (inventory pipeline), grown on demand */
+    void *d_inv = nullptr;
+    size_t inv_bytes = 0;
+
     /* scratch of the fleet pipeline, grown on demand, freed with the context */
     void *d_fleet = nullptr;
     size_t fleet_bytes = 0;

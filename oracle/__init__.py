@@ -49,6 +49,8 @@ def oracle():
         lib.orc_has_hw_alias.argtypes = [ctypes.c_char_p]
         lib.orc_fleet_roots.restype = u64
         lib.orc_fleet_roots.argtypes = [_vp, _vp, u32, _vp, _vp, u32, _vp, _vp, _vp, _vp, _vp, _vp]
+        lib.orc_fleet_roots_bound.restype = u64
+        lib.orc_fleet_roots_bound.argtypes = [_vp, _vp, u32, _vp, _vp, _vp, u32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.orc_alias_match_list.restype = u64
         lib.orc_alias_match_list.argtypes = [_vp, _vp, u32, _vp, _vp, u32, ctypes.c_int, u32, _vp, _vp]
         lib.orc_device_filter.restype = None
@@ -237,20 +239,25 @@ def safe_name(name):
     return bool(oracle().orc_safe_name(name.encode() if isinstance(name, str) else name))
 
 
-def fleet_roots(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe_name_bits, hw_alias):
+def fleet_roots(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe_name_bits, hw_alias, bound_mod=None):
     """(root_off, root_ids) of the per-host dashboard loop; driver_mod[i] is the
-    module device i resolves to (NO_MATCH = none)."""
+    module device i resolves to (NO_MATCH = none).  With bound_mod the used drivers are
+    the modules named like the devices' bound drivers (reference desktop/ui.py:1358-1359)."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
     dev_off = np.ascontiguousarray(dev_off, dtype=np.uint32)
     extra_off = np.ascontiguousarray(extra_off, dtype=np.uint32)
     V, H = len(rowptr) - 1, len(dev_off) - 1
     root_off = np.zeros(H + 1, dtype=np.uint32)
-    args = [_p(rowptr), _p(_c(col, np.uint32)), V, _p(_c(driver_mod, np.uint32)), _p(dev_off), H,
-            _p(extra_off), _p(_c(extra_ids, np.uint32)), _p(_c(safe_name_bits, np.uint8)),
-            _p(_c(hw_alias, np.uint8)), _p(root_off)]
-    total = oracle().orc_fleet_roots(*args, None)
+    args = [_p(rowptr), _p(_c(col, np.uint32)), V, _p(_c(driver_mod, np.uint32))]
+    fn = oracle().orc_fleet_roots
+    if bound_mod is not None:
+        args.append(_p(_c(bound_mod, np.uint32)))
+        fn = oracle().orc_fleet_roots_bound
+    args += [_p(dev_off), H, _p(extra_off), _p(_c(extra_ids, np.uint32)), _p(_c(safe_name_bits, np.uint8)),
+             _p(_c(hw_alias, np.uint8)), _p(root_off)]
+    total = fn(*args, None)
     ids = np.zeros(max(total, 1), dtype=np.uint32)
-    oracle().orc_fleet_roots(*args, _p(ids))
+    fn(*args, _p(ids))
     return root_off, ids[:total]
 
 

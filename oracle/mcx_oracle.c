@@ -418,11 +418,17 @@ static int orc_cmp_u32(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
-uint64_t orc_fleet_roots(const uint32_t *rowptr, const uint32_t *col, uint32_t V,
-                         const uint32_t *driver_mod, const uint32_t *dev_off, uint32_t H,
-                         const uint32_t *extra_off, const uint32_t *extra_ids,
-                         const uint8_t *safe_name, const uint8_t *hw_alias,
-                         uint32_t *root_off, uint32_t *root_ids)
+/* bound_mod == NULL: the used drivers are the modules the devices resolve to (above).
+ * Otherwise they are what reference desktop/ui.py:1358-1359 collects: the driver bound
+ * to each listed device, bound_mod[i] = the module named exactly like it (0xFFFFFFFF:
+ * unbound, or a driver name that is no module name - ui.py:1567 compares the strings as
+ * they are); the module a device resolves to is then loaded but not used. */
+static uint64_t fleet_roots_impl(const uint32_t *rowptr, const uint32_t *col, uint32_t V,
+                                 const uint32_t *driver_mod, const uint32_t *bound_mod,
+                                 const uint32_t *dev_off, uint32_t H,
+                                 const uint32_t *extra_off, const uint32_t *extra_ids,
+                                 const uint8_t *safe_name, const uint8_t *hw_alias,
+                                 uint32_t *root_off, uint32_t *root_ids)
 {
     /* per-host marks are stamped with h + 1 so nothing is cleared between hosts */
     uint32_t *used = (uint32_t *)calloc(V ? V : 1, sizeof(uint32_t));
@@ -435,12 +441,21 @@ uint64_t orc_fleet_roots(const uint32_t *rowptr, const uint32_t *col, uint32_t V
         uint32_t n = 0;
         for (uint32_t i = dev_off[h]; i < dev_off[h + 1]; ++i) {
             uint32_t m = driver_mod[i];
-            if (m >= V)
-                continue;
-            used[m] = stamp;
-            if (loaded[m] != stamp) {
-                loaded[m] = stamp;
-                list[n++] = m;
+            if (m < V) {
+                if (!bound_mod)
+                    used[m] = stamp;
+                if (loaded[m] != stamp) {
+                    loaded[m] = stamp;
+                    list[n++] = m;
+                }
+            }
+            uint32_t b = bound_mod ? bound_mod[i] : 0xFFFFFFFFu;
+            if (b < V) {
+                used[b] = stamp;
+                if (loaded[b] != stamp) {
+                    loaded[b] = stamp;
+                    list[n++] = b;
+                }
             }
         }
         for (uint32_t k = extra_off[h]; k < extra_off[h + 1]; ++k) {
@@ -479,6 +494,27 @@ uint64_t orc_fleet_roots(const uint32_t *rowptr, const uint32_t *col, uint32_t V
     free(held);
     free(list);
     return total;
+}
+
+uint64_t orc_fleet_roots(const uint32_t *rowptr, const uint32_t *col, uint32_t V,
+                         const uint32_t *driver_mod, const uint32_t *dev_off, uint32_t H,
+                         const uint32_t *extra_off, const uint32_t *extra_ids,
+                         const uint8_t *safe_name, const uint8_t *hw_alias,
+                         uint32_t *root_off, uint32_t *root_ids)
+{
+    return fleet_roots_impl(rowptr, col, V, driver_mod, NULL, dev_off, H, extra_off, extra_ids, safe_name, hw_alias,
+                            root_off, root_ids);
+}
+
+uint64_t orc_fleet_roots_bound(const uint32_t *rowptr, const uint32_t *col, uint32_t V,
+                               const uint32_t *driver_mod, const uint32_t *bound_mod,
+                               const uint32_t *dev_off, uint32_t H,
+                               const uint32_t *extra_off, const uint32_t *extra_ids,
+                               const uint8_t *safe_name, const uint8_t *hw_alias,
+                               uint32_t *root_off, uint32_t *root_ids)
+{
+    return fleet_roots_impl(rowptr, col, V, driver_mod, bound_mod, dev_off, H, extra_off, extra_ids, safe_name,
+                            hw_alias, root_off, root_ids);
 }
 
 /*

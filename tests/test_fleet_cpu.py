@@ -105,3 +105,32 @@ def test_fleet_oracle_vs_sets(oracle_mod):
         assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
         if V > 1:
             assert len(ids) > 0
+
+
+def test_driver_names_to_modules_are_compared_as_they_are():
+    """reference desktop/ui.py:1567 compares the driver string of a device record with the module
+    name unchanged: 'virtio-pci' is not module 'virtio_pci'"""
+    from montecarlo_amd import driver_modules
+
+    mods = ["virtio_pci", "e1000", "snd_hda_intel", "e1000", ""]
+    drv = ["virtio-pci", "virtio_pci", "e1000", "E1000", "snd_hda_intel", "None", "", "e1000e"]
+    assert driver_modules(drv, mods).tolist() == [0xFFFFFFFF, 0, 1, 0xFFFFFFFF, 2, 0xFFFFFFFF, 4, 0xFFFFFFFF]
+    assert driver_modules([], mods).tolist() == []
+    assert driver_modules(drv, []).tolist() == [0xFFFFFFFF] * len(drv)
+
+
+def test_oracle_bound_mode_by_hand(oracle_mod):
+    """three modules: 0 needs 1.  One host, two devices: one resolves to module 0 and is bound to
+    it, the other resolves to module 2 and is unbound.  Bound mode lists 2 (loaded, not used,
+    nobody holds it); alias mode lists nothing (0 and 2 are both used, 1 is held)."""
+    rowptr = np.array([0, 1, 1, 1], np.uint32)
+    col = np.array([1], np.uint32)
+    resolved = np.array([0, 2], np.uint32)
+    dev_off, extra_off = np.array([0, 2], np.uint32), np.array([0, 0], np.uint32)
+    ones = np.ones(3, np.uint8)
+    off, ids = oracle_mod.fleet_roots(rowptr, col, resolved, dev_off, extra_off, np.zeros(0, np.uint32), ones, ones)
+    assert ids.tolist() == []
+    bound = np.array([0, 0xFFFFFFFF], np.uint32)
+    off, ids = oracle_mod.fleet_roots(rowptr, col, resolved, dev_off, extra_off, np.zeros(0, np.uint32), ones, ones,
+                                      bound_mod=bound)
+    assert off.tolist() == [0, 1] and ids.tolist() == [2]

@@ -196,3 +196,115 @@ def test_inventory_to_lists_in_one_call(gpu_ctx, oracle_mod, cap_per_host):
     assert np.array_equal(d_rid.download(np.uint32, total), w_ids)
     for buf in bufs + [d_v, d_roff, d_rid]:
         buf.free()
+
+
+def _bound_case(seed, P, H, mean_dev, max_extra):
+    """a fleet with drivers bound by name: most devices are bound to the module their modalias
+    resolves to; some resolve and stay unbound; some are bound to a driver whose name is the
+    module's with dashes ('e1000-x' for module 'e1000_x': no module of that name), some to a
+    module other than the one the modalias names"""
+    f = make_fleet(seed, P, H, mean_dev, max_extra)
+    names = synth.module_names(seed + 4, f["V"])
+    first, _ = __import__("oracle").alias_match(f["A"], f["a_off"], f["S"], f["s_off"], use_twin=True)
+    resolved = np.where(first != NO_MATCH, f["a_mod"][np.minimum(first, len(f["a_mod"]) - 1)], NO_MATCH)
+    rng = np.random.default_rng(seed)
+    drivers = []                      # per device: the bound driver's name, None = unbound
+    for i in range(f["N"]):
+        r, m = rng.random(), int(resolved[i])
+        if m == NO_MATCH or r < 0.2:
+            drivers.append(None)
+        elif r < 0.3:
+            drivers.append(names[m].replace("_", "-"))
+        elif r < 0.4:
+            drivers.append(names[int(rng.integers(0, f["V"]))])
+        else:
+            drivers.append(names[m])
+    return f, names, resolved.astype(np.uint32), drivers
+
+
+@pytest.mark.parametrize("seed,P,H,mean_dev,max_extra", [(71, 3000, 200, 12, 4), (72, 600, 33, 5, 0)])
+def test_fleet_used_drivers_from_bound_names(gpu_ctx, oracle_mod, seed, P, H, mean_dev, max_extra):
+    """the reference's notion of a used driver (desktop/ui.py:1358-1359, 1567): the driver bound
+    to a device, compared with the module names as it stands"""
+    from montecarlo_amd import driver_modules
+
+    f, names, resolved, drivers = _bound_case(seed, P, H, mean_dev, max_extra)
+    by_name = {}
+    for v, n in enumerate(names):
+        by_name.setdefault(n, v)
+    want_bound = np.array([by_name.get(d, NO_MATCH) if d is not None else NO_MATCH for d in drivers], dtype=np.uint32)
+    # the library's name lookup, on the distinct driver names
+    distinct = sorted({d for d in drivers if d is not None})
+    drv_mod = driver_modules(distinct, names)
+    at = {d: k for k, d in enumerate(distinct)}
+    bound = np.array([drv_mod[at[d]] if d is not None else NO_MATCH for d in drivers], dtype=np.uint32)
+    assert np.array_equal(bound, want_bound)
+    assert any("-" in d for d in distinct) and (bound == NO_MATCH).sum() > (np.array(drivers) == None).sum()  # noqa: E711
+    hw = oracle_mod.hw_alias_flags(f["A"], f["a_off"], f["a_mod"], f["V"])
+    w_off, w_ids = oracle_mod.fleet_roots(f["rowptr"], f["col"], resolved, f["dev_off"], f["extra_off"],
+                                          f["extra_ids"], f["safe"], hw, bound_mod=want_bound)
+    gpu_ctx.alias_table_load(f["A"], f["a_off"], f["a_mod"])
+    gpu_ctx.dep_graph_load(f["rowptr"], f["col"])
+    off, ids = gpu_ctx.fleet_roots_bound(f["S"], f["s_off"], f["dev_off"], f["extra_off"], f["extra_ids"], f["safe"],
+                                         bound)
+    assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
+    # the other mode gives other lists: modules that resolved without binding show up here only
+    a_off, a_ids = run_fleet(gpu_ctx, f)
+    assert len(ids) > len(a_ids)
+    # all devices bound to what they resolve to: the two modes agree
+    off2, ids2 = gpu_ctx.fleet_roots_bound(f["S"], f["s_off"], f["dev_off"], f["extra_off"], f["extra_ids"],
+                                           f["safe"], resolved)
+    assert np.array_equal(off2, a_off) and np.array_equal(ids2, a_ids)
+
+
+def test_inventory_with_bound_drivers(gpu_ctx, oracle_mod):
+    """records -> device list -> module lists with the used drivers read from the records' driver
+    field through a name -> module map; the driver table mixes the names the device filter
+    looks for with module names, dashed variants and names that are no module"""
+    from montecarlo_amd import driver_modules
+
+    f = make_fleet(81, 3000, 250, 14, 4)
+    ctx, N, H, V = gpu_ctx, f["N"], f["H"], f["V"]
+    names = synth.module_names(85, V)
+    rec = synth.device_records(81, f["S"], f["s_off"])
+    base = [n for n in synth.DRIVER_NAMES]
+    table = base + names[:400] + [n.replace("_", "-") for n in names[400:450]] + ["no-such-module", ""]
+    arena, off = pack_strings([n.encode() for n in table])
+    rng = np.random.default_rng(81)
+    pick = rng.random(N) < 0.7
+    rec["driver"] = np.where(pick, rng.integers(0, len(table), size=N), rec["driver"]).astype(np.uint32)
+    drv_mod = driver_modules(table, names)
+    by_name = {}
+    for v, n in enumerate(names):
+        by_name.setdefault(n, v)
+    assert drv_mod.tolist() == [by_name.get(n, NO_MATCH) for n in table]
+    ctx.alias_table_load(f["A"], f["a_off"], f["a_mod"])
+    ctx.dep_graph_load(f["rowptr"], f["col"])
+    # expectation: the oracle's device list, then its per-host loop over the listed devices
+    o_v, o_kept = oracle_mod.device_filter(rec, arena, off, f["dev_off"], 0)
+    keep = np.nonzero(o_v & 1)[0]
+    raw = f["S"].tobytes()
+    Sk, sk_off = pack_strings([raw[f["s_off"][i]:f["s_off"][i + 1]] for i in keep])
+    first, _ = oracle_mod.alias_match(f["A"], f["a_off"], Sk, sk_off, use_twin=True)
+    resolved = np.where(first != NO_MATCH, f["a_mod"][np.minimum(first, len(f["a_mod"]) - 1)], NO_MATCH)
+    d = rec["driver"][keep]
+    bound = np.where(d < len(table), drv_mod[np.minimum(d, len(table) - 1)], NO_MATCH).astype(np.uint32)
+    hw = oracle_mod.hw_alias_flags(f["A"], f["a_off"], f["a_mod"], V)
+    w_off, w_ids = oracle_mod.fleet_roots(f["rowptr"], f["col"], resolved.astype(np.uint32), o_kept, f["extra_off"],
+                                          f["extra_ids"], f["safe"], hw, bound_mod=bound)
+    bufs = [ctx.to_device(x) for x in (rec, f["S"], f["s_off"], arena, off, drv_mod, f["dev_off"], f["extra_off"],
+                                       f["extra_ids"], f["safe"])]
+    d_rec, d_S, d_soff, d_arena, d_doff, d_dm, d_dev, d_xoff, d_xid, d_safe = bufs
+    d_v, d_roff = ctx.alloc(N), ctx.alloc(4 * (H + 1))
+    args = (d_rec.ptr, d_S.ptr, d_soff.ptr, N, d_arena.ptr, d_doff.ptr, len(table), d_dm.ptr, d_dev.ptr, H, 0,
+            d_xoff.ptr, d_xid.ptr, len(f["extra_ids"]), d_safe.ptr, d_v.ptr, d_roff.ptr)
+    total = ctx.fleet_inventory_roots_bound_dev(*args, None, 0, size_only=True)
+    assert total == len(w_ids) and total > 0
+    d_rid = ctx.alloc(4 * total)
+    for _ in range(2):   # twice: the second call reuses the context's buffers
+        assert ctx.fleet_inventory_roots_bound_dev(*args, d_rid.ptr, total) == total
+        assert np.array_equal(d_v.download(np.uint8, N) & 3, o_v)
+        assert np.array_equal(d_roff.download(np.uint32, H + 1), w_off)
+        assert np.array_equal(d_rid.download(np.uint32, total), w_ids)
+    for buf in bufs + [d_v, d_roff, d_rid]:
+        buf.free()
