@@ -280,7 +280,7 @@ def bench_one_gpu(ctx, synth, args, torch, stream, fence, local_rank):
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(N, P),
-            "kernel": "k1_match_indexed, one launch per step, device time from HIP events on its stream",
+            "kernel": "k1_match_small, one launch per step, device time from HIP events on its stream",
             "algorithmic_bytes_per_launch": alg_bytes,
             "device_us_per_launch": dev_s_per_launch * 1e6,
         },

@@ -49,7 +49,7 @@ struct mcx_ctx {
     uint64_t table_bytes = 0;
     bool bulk_min_set = false;       /* MCX_BULK_MIN was in the environment when the table was loaded */
     uint32_t bulk_min = 0;
-    bool k1_tiles = true;            /* large batches through the tile kernel (MCX_K1_TILES=0: the older one) */
+    bool list_two_pass = false;      /* MCX_LIST_TWO_PASS=1 when the table was loaded (test seam) */
 
     /* dependency graph: forward CSR as given, reverse CSR built at load */
     uint32_t V = 0, E = 0;

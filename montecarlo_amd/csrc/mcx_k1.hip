@@ -23,14 +23,10 @@
 #define K1_RING 2048u       /* survivors waiting for a program run, per block    */
 #define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
 #define K1_MAX_PATTERNS (1u << 26) /* survivor entries and group counts keep a pattern number in 26 bits */
-#define K1_CU_LDS_BYTES 163840u /* LDS of one gfx950 CU */
-#define K1_LDS_GRANULE 1280u    /* ... allocated to blocks in pieces of this size */
 #define MCX_ZERO_COPY_MAX ((size_t)2048 << 10) /* host-buffer calls up to this size: the kernel works on pinned host memory */
-#define K1_QUARTER 64u
-#define K1_LANEMAP 512u  /* screening lanes the small groups of one block can take */
-#define K1_BIGLIST 32u   /* (string, large group) pairs of one block that go through the second index */
-#define K1_LANE_NONE 0xFFFFu      /* a group of at most this many patterns takes a quarter of a
-                               step (16 lanes): four such groups share one          */
+#define K1_QUARTER 64u   /* a group of at most this many patterns takes a quarter of a
+                            screening step (16 lanes): four such groups share one */
+#define K1_LANEMAP 512u  /* small groups of one block that can share steps         */
 #define K1_GROUP 16u        /* survivors one wave stages per pass                 */
 #define K1_SUB 8u           /* of which it runs eight at a time, eight lanes each */
 #define K1_STAGE_STRIDE (MCX_SLOT_WORDS + 1u) /* odd: lanes reading the same word
@@ -62,6 +58,10 @@ struct k1_list_t {
     uint32_t *idx;
     const uint32_t *dup_start; /* per slot: its copies in dup_idx, for slots with a multiplicity above 1 */
     const uint32_t *dup_idx;
+    /* short lists (one pass): per string how many distinct pattern texts matched, and the first
+     * K1T_LIST_CAP of their slot numbers, in no particular order */
+    uint32_t *nslots;
+    uint32_t *slots;
 };
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
@@ -241,12 +241,10 @@ __device__ __attribute__((noinline)) void k1_normalize_tile(uint32_t *str_w, con
     }
 }
 
-template <bool BULK, bool LIST>
 __global__ void __launch_bounds__(K1_THREADS, 4)
-k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
-                 uint32_t str_cap, uint32_t s_aligned, uint32_t sub_cap, const k1_table_t T,
-                 uint32_t *__restrict__ first_idx,
-                 uint32_t *__restrict__ count, const k1_list_t L
+k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
+               uint32_t str_cap, uint32_t s_aligned, const k1_table_t T,
+               uint32_t *__restrict__ first_idx, uint32_t *__restrict__ count
 #ifdef MCX_K1_STAMPS
                  , unsigned long long *__restrict__ stamps
 #endif
@@ -270,17 +268,15 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     K1_STAMP(0);
     /* dynamic LDS, sized by the launch for its strings-per-block:
      * [spb occurrence tables][str_cap/4 + 5 words of string bytes]
-     * [hit_start][hit_cnt] of max_hits + sub_cap words each (hit_cnt: pattern
-     * count in bits 0..25, string slot above; the last sub_cap entries are the
-     * runs found through the second index), [hit_ub] of max_hits words */
+     * [hit_start][hit_cnt][hit_ub] of max_hits words each (hit_cnt: pattern
+     * count in bits 0..25, string slot above) */
     extern __shared__ __attribute__((aligned(16))) uint32_t k1_lds[];
     /* survivors waiting for a program run.  A round adds at most K1_WAVES x K1_UNIT and leaves
-     * less than K1_WAVES x GROUP behind; large batches take the smaller ring so that five
-     * blocks fit a CU's LDS whatever the table's number of key lengths */
-    constexpr uint32_t RING = BULK ? 1536u : K1_RING;
+     * less than K1_WAVES x GROUP behind */
+    constexpr uint32_t RING = K1_RING;
     __shared__ uint32_t ring[RING];
-    __shared__ uint32_t stage[BULK ? 1 : K1_WAVES][BULK ? 1 : K1_STAGE_WORDS];
-    constexpr uint32_t GROUP = BULK ? 64u : K1_GROUP; /* survivors one wave takes per pass */
+    __shared__ uint32_t stage[K1_WAVES][K1_STAGE_WORDS];
+    constexpr uint32_t GROUP = K1_GROUP; /* survivors one wave takes per pass */
     /* gram set of each string, one byte per bit number: the screen reads it with
      * byte loads at (set + bit), no shifts, and the gram pass fills it with plain
      * byte stores */
@@ -293,16 +289,12 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     uint32_t *occ_w = k1_lds;
     uint32_t *str_w = occ_w + spb * K1_OCC_WORDS;
     uint32_t *hit_start = str_w + str_cap / 4u + 5u;
-    uint32_t *hit_cnt = hit_start + max_hits + sub_cap;
-    uint32_t *hit_ub = hit_cnt + max_hits + sub_cap;
-    /* small groups (at most K1_QUARTER patterns) share screening steps: each takes one
-     * lane per four patterns; lane_map[g] = hit number << 4 | which four */
+    uint32_t *hit_cnt = hit_start + max_hits;
+    uint32_t *hit_ub = hit_cnt + max_hits;
+    /* small groups (at most K1_QUARTER patterns) share screening steps, a quarter of a step
+     * each: lane_map = their hit numbers */
     __shared__ uint16_t lane_map[K1_LANEMAP];
-    /* (string, large group) pairs: string slot | group number << 3, and the group's
-     * first pattern, size and number of patterns without an anchor gram */
-    __shared__ uint32_t big_slot[BULK ? K1_BIGLIST : 1u], big_start[BULK ? K1_BIGLIST : 1u],
-        big_count[BULK ? K1_BIGLIST : 1u], big_rest[BULK ? K1_BIGLIST : 1u];
-    __shared__ uint32_t nlanes_sh, nbiglist_sh, nsub_sh;
+    __shared__ uint32_t nlanes_sh;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -319,14 +311,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
      * string then sit in front of it in the buffer */
     const uint32_t shift = (use_lds && s_aligned) ? (gbase & 3u) : 0u;
 
-    /* Small batches: the probe of the index does not wait for the tile to be staged.  Its
+    /* The probe of the index does not wait for the tile to be staged.  Its
      * lanes (the last wave first) read the first bytes of their string straight from the
      * arena and walk the index while the other waves stage and build the gram sets; what
      * they found is recorded after the barrier.  (Not with kmod's dash rule, whose strings
      * are rewritten in LDS first, and not for an arena that cannot be read by words.) */
-    const bool early = !BULK && T.norm_dash == 0u && s_aligned != 0u;
+    const bool early = T.norm_dash == 0u && s_aligned != 0u;
     uint32_t e_start = 0, e_cnt = 0, e_slot = 0;
-    if constexpr (!BULK) {
+    {
         const uint32_t pr = (K1_THREADS - 1u) - tid;
         if (early && pr < nstr * T.nlens) {
             const uint32_t slot = T.nlens == 1u ? pr : __umulhi(pr, T.nlens_magic);
@@ -386,8 +378,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         uint32_t so = s_off[t0 + i];
         str_at[i] = so - gbase + shift;
         str_len[i] = s_off[t0 + i + 1] - so;
-        /* list variant: res_first holds where the string's list starts, res_count its fill */
-        res_first[i] = LIST ? L.off[t0 + i] : MCX_NO_MATCH;
+        res_first[i] = MCX_NO_MATCH;
         res_count[i] = 0;
         refused[i] = 0;
     }
@@ -402,8 +393,6 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         nhits = 0;
         nunits_sh = 0;
         nlanes_sh = 0;
-        nbiglist_sh = 0;
-        nsub_sh = 0;
         ring_cum[0] = 0;
         ring_cum[1] = 0;
     }
@@ -459,22 +448,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             /* the group's units take the next free places of the block's unit
              * space, in whatever order the hits arrive */
             ub = atomicAdd(&nunits_sh, (cnt + K1_UNIT - 1u) / K1_UNIT);
-        } else if constexpr (!BULK) {
-            /* small batches: a quarter of a shared unit per small group, whatever its
-             * size; lane_map is then the list of their hit numbers (one write here,
-             * on the block's critical path) */
-            lane_map[atomicAdd(&nlanes_sh, 1u)] = (uint16_t)h;
         } else {
-            const uint32_t nl = (cnt + 3u) / 4u, lb = atomicAdd(&nlanes_sh, nl);
-            if (lb + nl <= K1_LANEMAP) {
-                for (uint32_t t = 0; t < nl; ++t)
-                    lane_map[lb + t] = (uint16_t)((h << 4) | t);
-            } else {
-                /* the shared units are full: a unit of its own after all */
-                for (uint32_t g = lb; g < K1_LANEMAP; ++g)
-                    lane_map[g] = (uint16_t)K1_LANE_NONE;
-                ub = atomicAdd(&nunits_sh, 1u);
-            }
+            /* a quarter of a shared unit per small group, whatever its size; lane_map is the
+             * list of their hit numbers (one write here, on the block's critical path) */
+            const uint32_t q = atomicAdd(&nlanes_sh, 1u);
+            if (q < K1_LANEMAP)
+                lane_map[q] = (uint16_t)h;
+            else
+                ub = atomicAdd(&nunits_sh, 1u); /* the shared steps are full: a unit of its own */
         }
         hit_ub[h] = ub;
     };
@@ -484,12 +465,10 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 #endif
     const uint32_t nprobe = nstr * T.nlens;
     uint32_t pr_first = (K1_THREADS - 1u) - tid;
-    if constexpr (!BULK) {
-        if (early) {
-            if (e_cnt)
-                emit_hit(e_start, e_cnt, e_slot);
-            pr_first += K1_THREADS; /* a block with more than K1_THREADS probes: the rest the usual way */
-        }
+    if (early) {
+        if (e_cnt)
+            emit_hit(e_start, e_cnt, e_slot);
+        pr_first += K1_THREADS; /* a block with more than K1_THREADS probes: the rest the usual way */
     }
     for (uint32_t pr = pr_first; pr < nprobe; pr += K1_THREADS) {
         /* pr / nlens; a table with a single key length has no 32-bit reciprocal */
@@ -518,18 +497,9 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 #ifdef MCX_K1_STAMPS
         pt1 = __builtin_amdgcn_s_memtime();
 #endif
-        [[maybe_unused]] const uint32_t my_tag = mcx_key_tag(a);
         for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
-            if constexpr (BULK) {
-                /* most probes end at an empty slot: a large batch asks the tag bytes (which
-                 * stay in L2) first and spares itself the 64-byte entry; a small batch would
-                 * only lengthen its chain of dependent loads */
-                const uint32_t tag = T.tags[at];
-                if (tag == 0u)
-                    break;
-                if (tag != my_tag)
-                    continue;
-            }
+            /* the 64-byte entry at once: the tag bytes the large-batch kernel asks first would
+             * only lengthen this kernel's chain of dependent loads */
             const mcx_slot_t sl = T.slots[at];
             if (sl.count == 0u)
                 break;
@@ -538,22 +508,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
                 same = same && sl.key[k] == kw[k];
             if (same) {
-                bool listed = false;
-                if constexpr (BULK) {
-                    /* a group with a second index: looked up by the string's grams below */
-                    if (sl.pad[0] != 0u && sub_cap != 0u && use_lds && len <= MCX_OCC_MAX_LEN) {
-                        const uint32_t bi = atomicAdd(&nbiglist_sh, 1u);
-                        if (bi < K1_BIGLIST) {
-                            big_slot[bi] = slot | ((sl.pad[0] - 1u) << 3);
-                            big_start[bi] = sl.start;
-                            big_count[bi] = sl.count;
-                            big_rest[bi] = sl.pad[1];
-                            listed = true;
-                        }
-                    }
-                }
-                if (!listed)
-                    emit_hit(sl.start, sl.count, slot);
+                emit_hit(sl.start, sl.count, slot);
                 break;
             }
         }
@@ -566,119 +521,12 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
 #endif
     __syncthreads();
-    if constexpr (BULK) {
-        K1_STAMP(7);
-        /* ---- large groups through their second index: a wave per (string, group),
-         * a lane per four-byte window of the string.  Every pattern of the group
-         * outside its head names a gram it needs; the runs of the grams the string
-         * holds are the only candidates, and they come as small groups.  When the
-         * block's room for them is used up the whole group is screened instead. */
-        const uint32_t nb = min(nbiglist_sh, K1_BIGLIST);
-        /* what happens to one pair once its lanes know their runs */
-        auto sub_finish = [&](uint32_t slot, uint32_t gstart, uint32_t gcount, uint32_t rest, bool found,
-                              uint32_t fstart, uint32_t fcnt) __attribute__((always_inline)) {
-            /* a gram that occurs twice in the string names its run once; the runs get
-             * consecutive entries (64 patterns each) and lanes (four patterns each) */
-            const uint32_t pieces = (fcnt + K1_QUARTER - 1u) / K1_QUARTER, nl = (fcnt + 3u) / 4u;
-            uint32_t my_e = 0, my_l = 0, tot_e = 0, tot_l = 0;
-            unsigned long long todo = __ballot(found);
-            while (todo) {
-                const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(todo));
-                const uint32_t s = __builtin_amdgcn_readlane(fstart, l);
-                const bool same = found && fstart == s;
-                const unsigned long long sm = __ballot(same);
-                if (same && lane != l)
-                    found = false;
-                if (lane == l) {
-                    my_e = tot_e;
-                    my_l = tot_l;
-                }
-                tot_e += __builtin_amdgcn_readlane(pieces, l);
-                tot_l += __builtin_amdgcn_readlane(nl, l);
-                todo &= ~sm;
-            }
-            uint32_t ebase = 0, lbase = 0;
-            if (lane == 0) {
-                ebase = atomicAdd(&nsub_sh, tot_e);
-                lbase = atomicAdd(&nlanes_sh, tot_l);
-            }
-            ebase = __builtin_amdgcn_readfirstlane(ebase);
-            lbase = __builtin_amdgcn_readfirstlane(lbase);
-            if (ebase + tot_e <= sub_cap && lbase + tot_l <= K1_LANEMAP) {
-                if (lane == 0 && rest != 0u)
-                    emit_hit(gstart, rest, slot);
-                if (found) {
-                    for (uint32_t i = 0; i < pieces; ++i) {
-                        const uint32_t h = max_hits + ebase + my_e + i;
-                        const uint32_t c = min(K1_QUARTER, fcnt - K1_QUARTER * i);
-                        hit_start[h] = fstart + K1_QUARTER * i;
-                        hit_cnt[h] = c | (slot << 26);
-                        for (uint32_t t = 0; t < (c + 3u) / 4u; ++t)
-                            lane_map[lbase + my_l + 16u * i + t] = (uint16_t)((h << 4) | t);
-                    }
-                }
-            } else {
-                /* no room: give back nothing (later pairs fail the same way), blank the
-                 * lanes that were taken and screen the whole group */
-                const uint32_t gend = lbase + tot_l < K1_LANEMAP ? lbase + tot_l : K1_LANEMAP;
-                for (uint32_t g = lbase + lane; g < gend; g += 64u)
-                    lane_map[g] = (uint16_t)K1_LANE_NONE;
-                if (lane == 0)
-                    emit_hit(gstart, gcount, slot);
-            }
-        };
-        /* two pairs a wave at a time: the first tag is asked for both before either is used */
-        for (uint32_t b0 = wave; b0 < nb; b0 += 2u * K1_WAVES) {
-            uint32_t w[2] = {0, 0}, gid[2] = {0, 0}, at[2] = {0, 0}, tag[2] = {0, 0};
-            bool act[2];
-#pragma unroll
-            for (uint32_t i = 0; i < 2u; ++i) {
-                const uint32_t b = b0 + i * K1_WAVES;
-                act[i] = false;
-                if (b < nb) {
-                    const uint32_t slot = big_slot[b] & 7u;
-                    gid[i] = big_slot[b] >> 3;
-                    if (lane + 4u <= str_len[slot]) {
-                        act[i] = true;
-                        w[i] = LdsStr{(lds_words_t)str_w, str_at[slot]}.word(lane);
-                        at[i] = mcx_sub_hash(w[i], gid[i]);
-                        tag[i] = T.sub_tags[at[i] & T.sub_mask];
-                    }
-                }
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < 2u; ++i) {
-                const uint32_t b = b0 + i * K1_WAVES;
-                if (b >= nb)
-                    break;
-                bool found = false;
-                uint32_t fstart = 0, fcnt = 0;
-                if (act[i]) {
-                    const uint32_t tg = mcx_key_tag(at[i]);
-                    uint32_t t = tag[i];
-                    for (uint32_t p = at[i] & T.sub_mask; t != 0u; p = (p + 1u) & T.sub_mask, t = T.sub_tags[p]) {
-                        if (t != tg)
-                            continue;
-                        const mcx_sub_t e = T.sub[p];
-                        if (e.gram == w[i] && e.gid == gid[i]) {
-                            found = true;
-                            fstart = e.start;
-                            fcnt = e.count;
-                            break;
-                        }
-                    }
-                }
-                sub_finish(big_slot[b] & 7u, big_start[b], big_count[b], big_rest[b], found, fstart, fcnt);
-            }
-        }
-        __syncthreads();
-    }
     K1_STAMP(2);
 
     /* ---- units -> survivors ----------------------------------------------- */
     const uint32_t nh = nhits;
     const uint32_t nbig = nunits_sh, nlanes = min(nlanes_sh, K1_LANEMAP);
-    const uint32_t nunits = nbig + (BULK ? (nlanes + 63u) / 64u : (nlanes + 3u) / 4u);
+    const uint32_t nunits = nbig + (nlanes + 3u) / 4u;
     /* the first 64 hits live in registers, one per lane */
     uint32_t my_ub = 0, my_units = 0, my_start = 0, my_cnt = 0, my_slot = 0;
     if (lane < nh) {
@@ -690,30 +538,18 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
     }
     /* unit u -> per lane: first of its four patterns, how many of the four exist, string slot.
      * Units below nbig are 256 consecutive patterns of one large group; the ones
-     * behind them hold small groups: a lane per four patterns (large batches)
-     * or a quarter of the unit per group (small batches). */
+     * behind them hold small groups, a quarter of the unit per group. */
     auto unit_at = [&](uint32_t u, uint32_t &pk, uint32_t &pn, uint32_t &pslot) __attribute__((always_inline)) {
         if (u >= nbig) {
             pk = 0;
             pn = 0;
             pslot = 0;
-            if constexpr (BULK) {
-                const uint32_t g = 64u * (u - nbig) + lane;
-                const uint32_t e = g < nlanes ? lane_map[g] : K1_LANE_NONE;
-                if (e != K1_LANE_NONE) {
-                    const uint32_t h = e >> 4, sub = 4u * (e & 15u), cs = hit_cnt[h], cnt = cs & 0x03FFFFFFu;
-                    pk = hit_start[h] + sub;
-                    pn = min(4u, cnt - sub);
-                    pslot = cs >> 26;
-                }
-            } else {
-                const uint32_t q = 4u * (u - nbig) + (lane >> 4), sub = 4u * (lane & 15u);
-                if (q < nlanes) {
-                    const uint32_t h = lane_map[q], cs = hit_cnt[h], cnt = cs & 0x03FFFFFFu;
-                    pk = hit_start[h] + sub;
-                    pn = cnt > sub ? min(4u, cnt - sub) : 0u;
-                    pslot = cs >> 26;
-                }
+            const uint32_t q = 4u * (u - nbig) + (lane >> 4), sub = 4u * (lane & 15u);
+            if (q < nlanes) {
+                const uint32_t h = lane_map[q], cs = hit_cnt[h], cnt = cs & 0x03FFFFFFu;
+                pk = hit_start[h] + sub;
+                pn = cnt > sub ? min(4u, cnt - sub) : 0u;
+                pslot = cs >> 26;
             }
             return;
         }
@@ -764,46 +600,12 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             return mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets);
         return mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len, T.norm_dash}, len, T.sets);
     };
-    /* pattern in slot kk (table position orig, mult copies of its text) matches string `slot` */
-    auto hit = [&](uint32_t slot, uint32_t kk, uint32_t orig, uint32_t mult) __attribute__((always_inline)) {
-        if constexpr (LIST) {
-            if (!refused[slot]) {
-                uint32_t *dst = L.idx + res_first[slot] + atomicAdd(&res_count[slot], mult);
-                if (mult == 1u) {
-                    dst[0] = orig;
-                } else {
-                    const uint32_t *src = L.dup_idx + L.dup_start[kk];
-                    for (uint32_t m = 0; m < mult; ++m)
-                        dst[m] = src[m];
-                }
-            }
-        } else {
-            atomicMin(&res_first[slot], orig);
-            atomicAdd(&res_count[slot], mult);
-        }
+    /* the pattern at table position orig (mult copies of its text) matches string `slot` */
+    auto hit = [&](uint32_t slot, uint32_t orig, uint32_t mult) __attribute__((always_inline)) {
+        atomicMin(&res_first[slot], orig);
+        atomicAdd(&res_count[slot], mult);
     };
-    uint32_t *my_stage = stage[BULK ? 0u : wave];
-    /* many strings per block: a lane per survivor, its slot read in place; the
-     * waves of the other blocks on the CU cover the memory latency */
-    auto run_lanes = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
-        if (lane < n) {
-            const uint32_t e = ring[(from + lane) % RING];
-            const uint32_t slot = e >> 26;
-            const uint32_t len = str_len[slot];
-            const uint32_t *sp = T.slot + (size_t)(e & 0x03FFFFFFu) * MCX_SLOT_WORDS;
-            const uint32_t hdr = sp[0];
-            const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
-            bool ok;
-            if (is_ext || !use_lds || len > MCX_OCC_MAX_LEN) {
-                ok = slow_match(is_ext ? T.ext : sp, is_ext ? sp[MCX_SLOT_DIR] : MCX_SLOT_BODY, hdr, slot, len);
-            } else {
-                LdsOcc occ{(lds_words_t)occ_w + slot * K1_OCC_WORDS};
-                ok = mcx_slot_match_occ(GlobalProg{sp}, occ, len, T.sets);
-            }
-            if (ok)
-                hit(slot, e & 0x03FFFFFFu, sp[1], sp[MCX_SLOT_MULT]);
-        }
-    };
+    uint32_t *my_stage = stage[wave];
     auto run_groups = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
         K1_TICK();
 #pragma unroll
@@ -882,7 +684,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
                 ok = pre && k == 7u && MCX_STATE_OK(state) != 0u;
             }
             if (ok)
-                hit(slot, ring[(from + g) % RING] & 0x03FFFFFFu, lp[1], lp[MCX_SLOT_MULT]);
+                hit(slot, lp[1], lp[MCX_SLOT_MULT]);
             K1_TOCK(acc_comb);
 #ifdef MCX_K1_STAMPS
             ++acc_n;
@@ -894,13 +696,6 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto run_survivors = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {
-        if constexpr (BULK)
-            run_lanes(from, n);
-        else
-            run_groups(from, n);
-    };
-
     /* the block walks the units in rounds of K1_WAVES (one unit per wave) */
     const uint32_t nrounds = (nunits + K1_WAVES - 1u) / K1_WAVES;
     /* Ring bookkeeping without a second barrier per round: survivors of round r
@@ -980,7 +775,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
             const uint32_t avail = tail - head;
             const uint32_t groups = (avail / GROUP) & ~(K1_WAVES - 1u);
             for (uint32_t g = wave; g < groups; g += K1_WAVES)
-                run_survivors(head + GROUP * g, GROUP);
+                run_groups(head + GROUP * g, GROUP);
             head += GROUP * groups;
             /* next round's survivors may only overwrite entries that have been
              * run: make sure of it when this round ran a large part of the ring */
@@ -995,7 +790,7 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
          * are dealt out in whole passes (eight groups of lanes, or 64 lanes)
          * and a wave without one stays out of the way of the other blocks'
          * waves on its SIMD */
-        constexpr uint32_t PASS = BULK ? 64u : K1_SUB;
+        constexpr uint32_t PASS = K1_SUB;
         const uint32_t avail = tail - head;
         const uint32_t passes = (avail + PASS - 1u) / PASS;
         const uint32_t share = PASS * ((passes + K1_WAVES - 1u) / K1_WAVES);
@@ -1003,16 +798,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
         if (from < avail) {
             const uint32_t mine = min(share, avail - from);
             for (uint32_t off = 0; off < mine; off += GROUP)
-                run_survivors(head + from + off, min(GROUP, mine - off));
+                run_groups(head + from + off, min(GROUP, mine - off));
         }
     }
     __syncthreads();
     K1_STAMP(5);
-    if constexpr (!LIST) {
-        for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
-            first_idx[t0 + i] = refused[i] ? MCX_NO_MATCH : res_first[i];
-            count[t0 + i] = refused[i] ? 0u : res_count[i];
-        }
+    for (uint32_t i = tid; i < nstr; i += K1_THREADS) {
+        first_idx[t0 + i] = refused[i] ? MCX_NO_MATCH : res_first[i];
+        count[t0 + i] = refused[i] ? 0u : res_count[i];
     }
     K1_STAMP(6);
 #ifdef MCX_K1_STAMPS
@@ -1066,7 +859,14 @@ k1_match_indexed(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_o
 #define K1T_SKIP 99
 #endif
 
-template <bool LIST>
+/* MODE 0: first_idx and count.  MODE 1: the same plus, per string, the slots of the pattern
+ * texts that matched (up to K1T_LIST_CAP, written to global memory as they are found): the match lists of
+ * nearly every string follow from those without a second pass.  MODE 2: every match is written
+ * into L.idx at the place L.off (the exclusive sums of a counting pass) gives its string. */
+#define K1T_LIST_CAP 16u
+#define K1_EMIT_NARROW 8u /* lists up to this length are written by one thread, longer ones by a wave */
+
+template <int MODE>
 __global__ void __launch_bounds__(K1T_THREADS, 4)
 k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
                uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
@@ -1077,6 +877,8 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
     __shared__ uint32_t str_at[K1T_MAX_SPB], str_len[K1T_MAX_SPB], refused[K1T_MAX_SPB];
     __shared__ uint32_t res_first[K1T_MAX_SPB], res_count[K1T_MAX_SPB];
     __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
+    constexpr bool LIST = MODE == 2;
+    __shared__ uint32_t lcount[MODE == 1 ? K1T_MAX_SPB : 1u]; /* matching pattern texts per string */
     /* candidate runs: first pattern, count (bits 0..25) | string slot (26..31); run_cum = exclusive sums */
     __shared__ uint32_t run_start[K1T_RCAP], run_cnt[K1T_RCAP], run_cum[K1T_RCAP + 1u];
     __shared__ uint32_t big_key[K1T_BCAP], big_start[K1T_BCAP], big_count[K1T_BCAP], big_rest[K1T_BCAP];
@@ -1101,6 +903,8 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
         res_first[i] = LIST ? L.off[t0 + i] : MCX_NO_MATCH;
         res_count[i] = 0u;
         refused[i] = 0u;
+        if constexpr (MODE == 1)
+            lcount[i] = 0u;
     }
     for (uint32_t w = tid; w < nstr * MCX_BLOOM_WORDS; w += K1T_THREADS) {
         /* strings read in place get a full set: their patterns are not screened */
@@ -1173,6 +977,12 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
         } else {
             atomicMin(&res_first[slot], orig);
             atomicAdd(&res_count[slot], mult);
+            if constexpr (MODE == 1) {
+                /* the short list itself goes straight to global memory: an entry or two per string */
+                const uint32_t at = atomicAdd(&lcount[slot], 1u);
+                if (at < K1T_LIST_CAP)
+                    L.slots[(size_t)(t0 + slot) * K1T_LIST_CAP + at] = kk;
+            }
         }
     };
 
@@ -1477,12 +1287,66 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
         for (uint32_t i = tid; i < nstr; i += K1T_THREADS) {
             first_idx[t0 + i] = refused[i] ? MCX_NO_MATCH : res_first[i];
             count[t0 + i] = refused[i] ? 0u : res_count[i];
+            if constexpr (MODE == 1)
+                L.nslots[t0 + i] = refused[i] ? 0u : lcount[i];
         }
     }
 }
 
-/* one thread per string: its list in ascending table order (lists are short:
- * a handful of entries; insertion sort in place) */
+/*
+ * Match lists from the short lists of a MODE 1 pass, one thread per string.  A matching
+ * pattern text stands for one table position, or for several (its copies, ascending in
+ * dup_idx): the string's list is the merge of these few ascending runs, cut at `want`
+ * entries (the size of the string's place in list_idx).  Strings with more matching
+ * texts than a short list holds are counted in *overflow and left alone.
+ */
+__global__ void __launch_bounds__(256)
+k1_list_emit(const uint32_t *__restrict__ nslots, const uint32_t *__restrict__ slots,
+             const uint32_t *__restrict__ slot_tab, const uint32_t *__restrict__ dup_start,
+             const uint32_t *__restrict__ dup_idx, const uint32_t *__restrict__ off, uint32_t N,
+             uint32_t *__restrict__ idx, uint32_t *__restrict__ overflow)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const uint32_t ns = nslots[i];
+    if (ns > K1T_LIST_CAP) {
+        atomicAdd(overflow, 1u);
+        return;
+    }
+    const uint32_t want = off[i + 1] - off[i];
+    if (want == 0u || want > K1_EMIT_NARROW)
+        return; /* nothing to write, or k1_list_emit_wide's */
+    const uint32_t *run[K1T_LIST_CAP];
+    uint32_t head[K1T_LIST_CAP], left[K1T_LIST_CAP];
+    for (uint32_t k = 0; k < ns; ++k) {
+        const uint32_t kk = slots[(size_t)i * K1T_LIST_CAP + k];
+        const uint32_t *sp = slot_tab + (size_t)kk * MCX_SLOT_WORDS;
+        const uint32_t mult = sp[MCX_SLOT_MULT];
+        left[k] = mult;
+        run[k] = mult > 1u ? dup_idx + dup_start[kk] : nullptr;
+        head[k] = mult > 1u ? run[k][0] : sp[1];
+    }
+    uint32_t *dst = idx + off[i];
+    for (uint32_t o = 0; o < want; ++o) {
+        uint32_t best = 0, bv = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < ns; ++k)
+            if (left[k] != 0u && head[k] <= bv) {
+                bv = head[k];
+                best = k;
+            }
+        dst[o] = bv;
+        if (--left[best] != 0u)
+            head[best] = *++run[best];
+    }
+}
+
+/* Lists in ascending table order, in place.  Short lists: one thread each, insertion sort.
+ * Long lists (a string that hundreds or thousands of patterns match): one block each, bitonic
+ * merge network over the next power of two with every exchange ascending, so that the places
+ * past the list's end act as +infinity and never move. */
+#define K1_SORT_SHORT 32u
+
 __global__ void __launch_bounds__(256)
 k1_list_sort(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__restrict__ idx)
 {
@@ -1491,6 +1355,8 @@ k1_list_sort(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__restrict_
         return;
     uint32_t *a = idx + off[i];
     const uint32_t n = off[i + 1] - off[i];
+    if (n > K1_SORT_SHORT)
+        return; /* k1_list_sort_long's */
     for (uint32_t k = 1; k < n; ++k) {
         const uint32_t v = a[k];
         uint32_t j = k;
@@ -1503,11 +1369,136 @@ k1_list_sort(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__restrict_
 }
 
 __global__ void __launch_bounds__(256)
-k1_list_cap(const uint32_t *__restrict__ count, uint32_t N, uint32_t K, uint32_t *__restrict__ capped)
+k1_list_sort_long(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__restrict__ idx)
+{
+    for (uint32_t i = blockIdx.x; i < N; i += gridDim.x) {
+        const uint32_t n = off[i + 1] - off[i];
+        if (n <= K1_SORT_SHORT)
+            continue; /* the same for the whole block */
+        uint32_t *a = idx + off[i];
+        uint32_t m = 1;
+        while (m < n)
+            m <<= 1;
+        for (uint32_t k = 2; k <= m; k <<= 1) {
+            /* first step of a stage pairs x with its mirror image inside the block of k
+             * places, the later ones x with x ^ j: every pair in ascending order */
+            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                for (uint32_t x = threadIdx.x; x < m; x += blockDim.x) {
+                    const uint32_t y = j == (k >> 1) ? (x ^ (k - 1u)) : (x ^ j);
+                    if (y > x && y < n) {
+                        const uint32_t ax = a[x], ay = a[y];
+                        if (ax > ay) {
+                            a[x] = ay;
+                            a[y] = ax;
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+    }
+}
+
+/*
+ * The same for the strings with longer lists (a pattern text with dozens of copies in the
+ * table), a wave per string: every table position of every run computes its own place in
+ * the merged list - its place in its run plus, for each other run, the number of entries
+ * below it (bisection) - and is written there if that place is inside the list.
+ */
+__global__ void __launch_bounds__(256)
+k1_list_emit_wide(const uint32_t *__restrict__ nslots, const uint32_t *__restrict__ slots,
+                  const uint32_t *__restrict__ slot_tab, const uint32_t *__restrict__ dup_start,
+                  const uint32_t *__restrict__ dup_idx, const uint32_t *__restrict__ off, uint32_t N,
+                  uint32_t *__restrict__ idx)
+{
+    __shared__ const uint32_t *rptr[4][K1T_LIST_CAP];
+    __shared__ uint32_t rlen[4][K1T_LIST_CAP], rhead[4][K1T_LIST_CAP], rbase[4][K1T_LIST_CAP + 1u];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 4u + wave;
+    if (i >= N)
+        return;
+    const uint32_t ns = nslots[i], want = off[i + 1] - off[i];
+    if (ns > K1T_LIST_CAP || want <= K1_EMIT_NARROW)
+        return; /* the same for the whole wave */
+    if (lane < ns) {
+        const uint32_t kk = slots[(size_t)i * K1T_LIST_CAP + lane];
+        const uint32_t *sp = slot_tab + (size_t)kk * MCX_SLOT_WORDS;
+        const uint32_t mult = sp[MCX_SLOT_MULT];
+        rlen[wave][lane] = mult;
+        rptr[wave][lane] = mult > 1u ? dup_idx + dup_start[kk] : nullptr;
+        rhead[wave][lane] = sp[1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0u) {
+        uint32_t at = 0;
+        for (uint32_t k = 0; k < ns; ++k) {
+            rbase[wave][k] = at;
+            at += rlen[wave][k];
+        }
+        rbase[wave][ns] = at;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t total = rbase[wave][ns];
+    uint32_t *dst = idx + off[i];
+    for (uint32_t e = lane; e < total; e += 64u) {
+        uint32_t r = 0;
+        while (rbase[wave][r + 1u] <= e)
+            ++r;
+        const uint32_t p = e - rbase[wave][r];
+        const uint32_t v = rlen[wave][r] > 1u ? rptr[wave][r][p] : rhead[wave][r];
+        uint32_t rank = p;
+        for (uint32_t o = 0; o < ns; ++o) {
+            if (o == r)
+                continue;
+            if (rlen[wave][o] == 1u) {
+                rank += rhead[wave][o] < v ? 1u : 0u;
+            } else {
+                const uint32_t *q = rptr[wave][o];
+                uint32_t lo = 0, hi = rlen[wave][o]; /* entries of run o below v */
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (q[mid] < v)
+                        lo = mid + 1u;
+                    else
+                        hi = mid;
+                }
+                rank += lo;
+            }
+        }
+        if (rank < want)
+            dst[rank] = v;
+    }
+}
+
+/* capped[i] = min(count[i], K) (K = 0: no limit, nothing written), and the number of strings
+ * whose short list overflowed */
+__global__ void __launch_bounds__(256)
+k1_list_cap(const uint32_t *__restrict__ count, const uint32_t *__restrict__ nslots, uint32_t N, uint32_t K,
+            uint32_t *__restrict__ capped, uint32_t *__restrict__ overflow)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N)
-        capped[i] = count[i] < K ? count[i] : K;
+    bool over = false;
+    if (i < N) {
+        if (K)
+            capped[i] = count[i] < K ? count[i] : K;
+        over = nslots[i] > K1T_LIST_CAP;
+    }
+    const unsigned long long m = __ballot(over);
+    if (m && (threadIdx.x & 63u) == 0u)
+        atomicAdd(overflow, (uint32_t)__popcll(m));
+}
+
+/* two 64-bit totals from device memory into pinned host memory (one small launch is quicker
+ * than a device-to-host copy) */
+__global__ void k1_publish2(const unsigned long long *__restrict__ d, unsigned long long *__restrict__ h)
+{
+    if (threadIdx.x < 2u)
+        h[threadIdx.x] = d[threadIdx.x];
 }
 
 /* the first entries of every sorted list: from[i] .. -> to[i] .. to[i+1] */
@@ -1609,8 +1600,8 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
         const char *env = getenv("MCX_BULK_MIN");
         ctx->bulk_min_set = env && *env;
         ctx->bulk_min = ctx->bulk_min_set ? (uint32_t)strtoul(env, nullptr, 10) : 0u;
-        const char *tiles = getenv("MCX_K1_TILES");
-        ctx->k1_tiles = !(tiles && tiles[0] == '0');
+        const char *two = getenv("MCX_LIST_TWO_PASS"); /* test seam: match lists by count + fill always */
+        ctx->list_two_pass = two && two[0] == '1';
     }
     ctx->table_loaded = true;
     return MCX_OK;
@@ -1645,41 +1636,8 @@ extern "C" int mcx_debug_k1_stamps(unsigned long long *out, uint32_t max_blocks)
 /* list_off == nullptr: first_idx / count.  Otherwise the list variant: every
  * match is written into d_list_idx at the place list_off (the exclusive sums
  * of a counting pass over the same strings) gives its string. */
-/* Which of the two variants of the kernel a batch gets.  Eight lanes per survivor
- * while a block's waves see few survivors at a time, a lane per survivor once every
- * pass fills its wave: measured against 3 x 10^4 patterns the two meet at about
- * 16 000 strings.  Only the large-batch variant uses the second index of the large
- * groups, and against a table with a very large group (every "of:" line of a table of
- * 3 x 10^6 patterns shares one prefix) that decides it whatever the batch: 1000 strings
- * take 25 us with it and 78 us without (equal at 3 x 10^5 patterns, largest group 11 800);
- * in between, 12 000 strings against 10^5 patterns take 45 us with it and 54 us without.
- * Test seam: MCX_BULK_MIN in the environment, read once when the table is loaded, replaces
- * the batch size (results do not depend on the variant). */
-static bool k1_use_bulk(const mcx_ctx *ctx, uint32_t N)
+static void k1_fill_table(const mcx_ctx *ctx, k1_table_t &T)
 {
-    if (ctx->bulk_min_set)
-        return N >= ctx->bulk_min;
-    if (N >= 16384u)
-        return true;
-    /* the larger the largest group, the earlier the second index pays: 7000 strings against
-     * 10^5 patterns (largest group 3900), any batch from 8192 patterns in one group on */
-    return ctx->n_sub_groups != 0u &&
-           (ctx->max_group >= 8192u || (uint64_t)N * ctx->max_group >= 24000000ull);
-}
-
-static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
-                              uint32_t *d_first, uint32_t *d_count, const uint32_t *d_list_off = nullptr,
-                              uint32_t *d_list_idx = nullptr)
-{
-    if (N == 0)
-        return MCX_OK;
-    /* few strings: one per block, so that the whole chip has work;
-     * many strings: up to K1_MAX_SPB per block */
-    uint32_t spb = (N + 2047u) / 2048u;
-    if (spb > K1_MAX_SPB)
-        spb = K1_MAX_SPB;
-    uint32_t blocks = (N + spb - 1u) / spb;
-    k1_table_t T;
     T.slot = ctx->d_slot;
     T.ext = ctx->d_ext;
     T.sig = ctx->d_sig;
@@ -1694,6 +1652,52 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     T.nlens = ctx->nlens;
     T.nlens_magic = ctx->nlens ? (uint32_t)((((uint64_t)1 << 32) + ctx->nlens - 1u) / ctx->nlens) : 0u;
     T.norm_dash = ctx->norm_dash ? 1u : 0u;
+}
+
+/* Which of the two kernels a batch gets.  The small-batch kernel (a handful of strings per
+ * block, occurrence tables, eight lanes per program run) is faster while the batch does not
+ * fill the chip several times over; the tile kernel (up to 64 strings per block) from about
+ * 24 000 strings on (measured against 3 x 10^4 patterns: 46 / 56 us at 16 384 strings, 92 /
+ * 70 us at 32 768).  Only the tile kernel uses the second index of the large groups, and
+ * against a table with a very large group (every "of:" line of a table of 3 x 10^6 patterns
+ * shares one prefix) that decides it whatever the batch: 1000 strings take 28 us with it
+ * and 78 us without.  Test seam: MCX_BULK_MIN in the environment, read once when the table
+ * is loaded, replaces the batch size (results do not depend on the kernel). */
+static bool k1_use_tiles(const mcx_ctx *ctx, uint32_t N)
+{
+    if (ctx->bulk_min_set)
+        return N >= ctx->bulk_min;
+    if (N >= 24576u)
+        return true;
+    /* the larger the largest group, the earlier the second index pays: 7000 strings against
+     * 10^5 patterns (largest group 3900), any batch from 8192 patterns in one group on */
+    return ctx->n_sub_groups != 0u &&
+           (ctx->max_group >= 8192u || (uint64_t)N * ctx->max_group >= 24000000ull);
+}
+
+static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
+                              uint32_t *d_first, uint32_t *d_count)
+{
+    if (N == 0)
+        return MCX_OK;
+    k1_table_t T;
+    k1_fill_table(ctx, T);
+    const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
+    /* few strings: one per block, so that the whole chip has work; many: more per block */
+    uint32_t spb = (N + 2047u) / 2048u;
+#ifndef MCX_K1_STAMPS
+    if (k1_use_tiles(ctx, N)) {
+        if (spb > K1T_MAX_SPB)
+            spb = K1T_MAX_SPB;
+        k1_match_tiles<0><<<(N + spb - 1u) / spb, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, spb, s_aligned, T,
+                                                                                  d_first, d_count, k1_list_t{});
+        HIPCHK(ctx, hipGetLastError());
+        return MCX_OK;
+    }
+#endif
+    if (spb > K1_MAX_SPB)
+        spb = K1_MAX_SPB;
+    const uint32_t blocks = (N + spb - 1u) / spb;
     /* staging buffer: 256 bytes per string of the tile, between 1 KiB and 8 KiB;
      * a tile that needs more is read in place */
     uint32_t str_cap = spb * 256u;
@@ -1701,53 +1705,7 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         str_cap = 1024u;
     if (str_cap > K1_LDS_STR_BYTES)
         str_cap = K1_LDS_STR_BYTES;
-    /* five blocks of a large batch fit one CU's LDS with a few hundred bytes to spare: nothing
-     * may be added to this without looking at the occupancy.  A table with many key lengths
-     * has larger hit arrays; the staging buffer then gives way (down to 128 bytes per string)
-     * so that the fifth block still fits. */
-    const bool bulk = k1_use_bulk(ctx, N);
-    const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
-#ifndef MCX_K1_STAMPS
-    if (bulk && ctx->k1_tiles) {
-        /* tiles of up to 64 strings, as many as leave every CU a few blocks */
-        uint32_t tspb = (N + 2047u) / 2048u;
-        if (tspb > K1T_MAX_SPB)
-            tspb = K1T_MAX_SPB;
-        const uint32_t tblocks = (N + tspb - 1u) / tspb;
-        const k1_list_t TL{d_list_off, d_list_idx, ctx->d_dup_start, ctx->d_dup_idx};
-        if (d_list_off)
-            k1_match_tiles<true><<<tblocks, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, tspb, s_aligned, T,
-                                                                           nullptr, nullptr, TL);
-        else
-            k1_match_tiles<false><<<tblocks, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, tspb, s_aligned, T,
-                                                                            d_first, d_count, TL);
-        HIPCHK(ctx, hipGetLastError());
-        return MCX_OK;
-    }
-#endif
-    uint32_t sub_cap = 0; /* entries for the runs found through the second index (large batches) */
-    auto lds_bytes = [&](uint32_t cap, uint32_t subs) {
-        return 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)cap / 4 + 5 + 3 * (size_t)spb * T.nlens + 2 * (size_t)subs + 1);
-    };
-    if (bulk) {
-        static size_t static_lds = 0; /* the same value whichever thread writes it */
-        if (!static_lds) {
-            hipFuncAttributes fa;
-            HIPCHK(ctx, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k1_match_indexed<true, false>)));
-            static_lds = fa.sharedSizeBytes;
-        }
-        /* LDS is handed out in granules: five blocks get 25 of the CU's 128 each */
-        const size_t budget = (K1_CU_LDS_BYTES / K1_LDS_GRANULE / 5u) * K1_LDS_GRANULE;
-        const uint32_t want = ctx->n_sub_groups ? 64u : 0u; /* the least that makes the second index worth it */
-        while (static_lds + lds_bytes(str_cap, want) > budget && str_cap > spb * 128u)
-            str_cap -= 256u;
-        if (want && static_lds + lds_bytes(str_cap, want) <= budget) {
-            sub_cap = (uint32_t)((budget - static_lds - lds_bytes(str_cap, 0)) / 8u);
-            if (sub_cap > 192u)
-                sub_cap = 192u;
-        }
-    }
-    size_t lds = lds_bytes(str_cap, sub_cap);
+    const size_t lds = 4 * ((size_t)spb * K1_OCC_WORDS + (size_t)str_cap / 4 + 5 + 3 * (size_t)spb * T.nlens + 1);
 #ifdef MCX_K1_STAMPS
     static uint32_t stamp_cap = 0;
     if (blocks > stamp_cap) {
@@ -1757,26 +1715,11 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
         stamp_cap = blocks;
     }
     g_k1_stamp_blocks = blocks;
-    if (bulk)
-        k1_match_indexed<true, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(
-            d_S, d_s_off, N, spb, str_cap, s_aligned, sub_cap, T, d_first, d_count, k1_list_t{}, g_k1_stamps);
-    else
-        k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(
-            d_S, d_s_off, N, spb, str_cap, s_aligned, sub_cap, T, d_first, d_count, k1_list_t{}, g_k1_stamps);
+    k1_match_small<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T, d_first,
+                                                             d_count, g_k1_stamps);
 #else
-    const k1_list_t L{d_list_off, d_list_idx, ctx->d_dup_start, ctx->d_dup_idx};
-    if (d_list_off && bulk)
-        k1_match_indexed<true, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                               s_aligned, sub_cap, T, nullptr, nullptr, L);
-    else if (d_list_off)
-        k1_match_indexed<false, true><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                                s_aligned, sub_cap, T, nullptr, nullptr, L);
-    else if (bulk)
-        k1_match_indexed<true, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                                s_aligned, sub_cap, T, d_first, d_count, L);
-    else
-        k1_match_indexed<false, false><<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap,
-                                                                                 s_aligned, sub_cap, T, d_first, d_count, L);
+    k1_match_small<<<blocks, K1_THREADS, lds, ctx->stream>>>(d_S, d_s_off, N, spb, str_cap, s_aligned, T, d_first,
+                                                             d_count);
 #endif
     HIPCHK(ctx, hipGetLastError());
     return MCX_OK;
@@ -1869,6 +1812,27 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
     return MCX_OK;
 }
 
+/* the tile kernel in one of its list modes over the whole batch */
+static int launch_tiles_list(mcx_ctx *ctx, int mode, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
+                             uint32_t *d_first, uint32_t *d_count, const k1_list_t &L)
+{
+    k1_table_t T;
+    k1_fill_table(ctx, T);
+    uint32_t spb = (N + 2047u) / 2048u;
+    if (spb > K1T_MAX_SPB)
+        spb = K1T_MAX_SPB;
+    const uint32_t blocks = (N + spb - 1u) / spb;
+    const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
+    if (mode == 1)
+        k1_match_tiles<1><<<blocks, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, spb, s_aligned, T, d_first,
+                                                                    d_count, L);
+    else
+        k1_match_tiles<2><<<blocks, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, spb, s_aligned, T, nullptr,
+                                                                    nullptr, L);
+    HIPCHK(ctx, hipGetLastError());
+    return MCX_OK;
+}
+
 int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, uint32_t K,
                              void *d_list_off, void *d_list_idx, uint64_t cap, uint64_t *total_out)
 {
@@ -1883,39 +1847,40 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
         HIPCHK(ctx, hipMemsetAsync(d_list_off, 0, 4, ctx->stream));
         return MCX_OK;
     }
-#ifdef MCX_K1_STAMPS
-    ctx->err = "the diagnostic build has no list variant";
-    return MCX_E_BAD_ARG;
-#else
     const uint32_t nb = (N + SCAN_ITEMS - 1u) / SCAN_ITEMS, grid = (N + 255u) / 256u;
-    /* scratch: first, count, offsets of the full lists, capped counts, block sums, two totals */
+    /* scratch: first, count, number of matching texts, capped counts, offsets of the full lists
+     * (fallback), block sums, totals, and the short lists */
     const size_t words = up256(4 * ((size_t)N + 1));
-    const size_t o_count = words, o_full = 2 * words, o_cap = 3 * words, o_bsum = 4 * words;
-    const size_t o_total = o_bsum + up256(4 * (size_t)nb);
+    const size_t o_count = words, o_ns = 2 * words, o_cap = 3 * words, o_full = 4 * words, o_bsum = 5 * words;
+    const size_t o_total = o_bsum + up256(4 * (size_t)nb), o_slots = o_total + 256;
     void *base;
-    int rc = mcx_scratch(ctx, o_total + 256, &base);
+    int rc = mcx_scratch(ctx, o_slots + up256(4 * (size_t)N * K1T_LIST_CAP), &base);
     if (rc != MCX_OK)
         return rc;
     uint32_t *d_first = (uint32_t *)base, *d_count = (uint32_t *)((char *)base + o_count);
-    uint32_t *d_full = (uint32_t *)((char *)base + o_full), *d_capped = (uint32_t *)((char *)base + o_cap);
-    uint32_t *d_bsum = (uint32_t *)((char *)base + o_bsum);
-    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
+    uint32_t *d_ns = (uint32_t *)((char *)base + o_ns), *d_capped = (uint32_t *)((char *)base + o_cap);
+    uint32_t *d_full = (uint32_t *)((char *)base + o_full), *d_bsum = (uint32_t *)((char *)base + o_bsum);
+    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total); /* [0] kept, [1] overflows */
+    uint32_t *d_over = (uint32_t *)(d_total + 1);
+    uint32_t *d_slots = (uint32_t *)((char *)base + o_slots);
     unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
-    /* counting pass, then the places of the lists */
-    if ((rc = launch_alias_match(ctx, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N, d_first, d_count)) != MCX_OK)
+    k1_list_t L{nullptr, nullptr, ctx->d_dup_start, ctx->d_dup_idx, d_ns, d_slots};
+    /* one pass: counts, first matches and the short lists; then the places of the lists */
+    HIPCHK(ctx, hipMemsetAsync(d_total, 0, 16, ctx->stream));
+    if ((rc = launch_tiles_list(ctx, 1, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N, d_first, d_count, L)) !=
+        MCX_OK)
         return rc;
-    uint32_t *full_off = K ? d_full : (uint32_t *)d_list_off;
-    mcx_scan_enqueue(ctx->stream, d_count, N, d_bsum, d_total, full_off);
-    if (K) {
-        k1_list_cap<<<grid, 256, 0, ctx->stream>>>(d_count, N, K, d_capped);
-        mcx_scan_enqueue(ctx->stream, d_capped, N, d_bsum, d_total + 1, (uint32_t *)d_list_off);
-    }
+    k1_list_cap<<<grid, 256, 0, ctx->stream>>>(d_count, d_ns, N, K, d_capped, d_over);
+    mcx_scan_enqueue(ctx->stream, K ? d_capped : d_count, N, d_bsum, d_total, (uint32_t *)d_list_off);
+    unsigned long long *dh_total = nullptr; /* the pinned words as the device addresses them */
+    HIPCHK(ctx, hipHostGetDevicePointer((void **)&dh_total, h_total, 0));
+    k1_publish2<<<1, 64, 0, ctx->stream>>>(d_total, dh_total);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(h_total, d_total, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long all = h_total[0], kept = K ? h_total[1] : all;
+    const unsigned long long kept = h_total[0];
+    const uint32_t overflows = (uint32_t)h_total[1];
     *total_out = kept;
-    if (all > 0xFFFFFFFFull) {
+    if (kept > 0xFFFFFFFFull) {
         ctx->err = "more than 2^32 - 1 matches: split the batch";
         return MCX_E_TOO_LARGE;
     }
@@ -1923,20 +1888,42 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
         ctx->err = "list_idx too small: " + std::to_string(kept) + " entries needed";
         return MCX_E_TOO_LARGE;
     }
-    if (all == 0)
+    if (kept == 0)
         return MCX_OK;
-    /* filling pass; with a limit the full lists go to a temporary array first */
-    uint32_t *full_idx = (uint32_t *)d_list_idx;
+    if (overflows == 0u && !ctx->list_two_pass) {
+        k1_list_emit<<<grid, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start, ctx->d_dup_idx,
+                                                    (const uint32_t *)d_list_off, N, (uint32_t *)d_list_idx, d_over);
+        k1_list_emit_wide<<<(N + 3u) / 4u, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start,
+                                                                 ctx->d_dup_idx, (const uint32_t *)d_list_off, N,
+                                                                 (uint32_t *)d_list_idx);
+        HIPCHK(ctx, hipGetLastError());
+        return MCX_OK;
+    }
+    /* some string is matched by more pattern texts than a short list holds (or the test seam
+     * asks for it): the lists are filled by a second pass of the kernel and sorted */
+    uint32_t *full_off = (uint32_t *)d_list_off, *full_idx = (uint32_t *)d_list_idx;
     if (K) {
+        mcx_scan_enqueue(ctx->stream, d_count, N, d_bsum, d_total, d_full);
+        k1_publish2<<<1, 64, 0, ctx->stream>>>(d_total, dh_total);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const unsigned long long all = h_total[0];
+        if (all > 0xFFFFFFFFull) {
+            ctx->err = "more than 2^32 - 1 matches: split the batch";
+            return MCX_E_TOO_LARGE;
+        }
         if (hipMalloc((void **)&full_idx, 4 * (size_t)all) != hipSuccess) {
             ctx->err = "hipMalloc of the full match lists failed";
             return MCX_E_NOMEM;
         }
+        full_off = d_full;
     }
-    rc = launch_alias_match(ctx, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N, nullptr, nullptr, full_off,
-                            full_idx);
+    L.off = full_off;
+    L.idx = full_idx;
+    rc = launch_tiles_list(ctx, 2, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N, nullptr, nullptr, L);
     if (rc == MCX_OK) {
         k1_list_sort<<<grid, 256, 0, ctx->stream>>>(full_off, N, full_idx);
+        k1_list_sort_long<<<N < 4096u ? N : 4096u, 256, 0, ctx->stream>>>(full_off, N, full_idx);
         if (K)
             k1_list_take<<<grid, 256, 0, ctx->stream>>>(full_off, full_idx, (const uint32_t *)d_list_off, N,
                                                         (uint32_t *)d_list_idx);
@@ -1948,7 +1935,6 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
         (void)hipFree(full_idx);
     }
     return rc;
-#endif
 }
 
 int mcx_alias_match_list(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, uint32_t K,

@@ -14,7 +14,7 @@ import os
 import sys
 
 
-def per_launch(directory, counter, kernel="k1_match_indexed"):
+def per_launch(directory, counter, kernel="k1_match_small"):
     vals = []
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
@@ -31,7 +31,7 @@ def main():
     fetch_kib, nf = per_launch(fetch_dir, "FETCH_SIZE")
     write_kib, nw = per_launch(write_dir, "WRITE_SIZE")
     rec = {
-        "strings": n, "patterns": p, "kernel": "k1_match_indexed",
+        "strings": n, "patterns": p, "kernel": "k1_match_small",
         "fetch_size_kib_median": fetch_kib, "write_size_kib_median": write_kib, "launches_sampled": [nf, nw],
         "hbm_bytes_per_launch": int(2 * fetch_kib * 1024 + write_kib * 1024),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/k1time.py; "

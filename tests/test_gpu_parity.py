@@ -123,6 +123,64 @@ def test_k1_match_lists(gpu_ctx, oracle_mod):
     assert off.tolist() == [0] and len(idx) == 0
 
 
+def test_k1_match_lists_long_and_both_ways(gpu_ctx, oracle_mod, monkeypatch):
+    """Lists come from one pass of the kernel while no string is matched by more than 16
+    different pattern texts, and from a second, filling pass otherwise.  Both ways on the same
+    batches (the seam forces the second one), a string matched by 17, by 40 and by more than
+    10 000 different patterns (long lists are sorted by a whole block), with and without a limit."""
+    import itertools
+
+    base = b"x:0123456789abcdefghij"
+    body = base[2:]
+    pats = [b"x:*"]
+    for r in (4, 5):
+        for pos in itertools.combinations(range(len(body)), r):
+            pats.append(b"x:*" + b"*".join(bytes([body[i]]) for i in pos) + b"*")
+            if len(pats) >= 12000:
+                break
+    pats += [b"y:*%d*" % d for d in range(10)] + [b"y:*%d*%d*" % (d, d + 1) for d in range(9)]
+    pats += [b"y:?%d*" % d for d in range(10)]                                          # 'y:' strings: up to 20 texts
+    pats += [b"z:*%02d" % d for d in range(40)] + [b"z:*"] * 3                            # copies of one text
+    rng = np.random.default_rng(3)
+    order = rng.permutation(len(pats))                 # table order is not the order they were made in
+    pats = [pats[i] for i in order]
+    A, a_off = pack_strings(pats)
+    strs = [base, b"x:", b"x:jihgfedcba9876543210", b"y:0123456789", b"y:5", b"y:55", b"z:07", b"z:", b"w:nothing"]
+    strs += [b"y:%d%d" % (a, b) for a in range(10) for b in range(10)]
+    S, s_off = pack_strings(strs)
+    o_off, o_idx = oracle_mod.alias_match_list(A, a_off, S, s_off)
+    assert o_off[1] - o_off[0] > 10_000 and 16 < o_off[4] - o_off[3] <= 20
+    for two_pass in ("0", "1"):
+        monkeypatch.setenv("MCX_LIST_TWO_PASS", two_pass)
+        gpu_ctx.alias_table_load(A, a_off, np.zeros(len(pats), dtype=np.uint32))
+        off, idx = gpu_ctx.alias_match_list(S, s_off)
+        assert np.array_equal(off, o_off) and np.array_equal(idx, o_idx)
+        for K in (1, 3, 17, 100):
+            k_off, k_idx = gpu_ctx.alias_match_list(S, s_off, K=K)
+            w_off, w_idx = oracle_mod.alias_match_list(A, a_off, S, s_off, K=K)
+            assert np.array_equal(k_off, w_off) and np.array_equal(k_idx, w_idx)
+        # without the long lists: short lists only, nothing overflows
+        short = [i for i in range(len(strs)) if o_off[i + 1] - o_off[i] <= 16]
+        Ss, ss_off = pack_strings([strs[i] for i in short])
+        off, idx = gpu_ctx.alias_match_list(Ss, ss_off, K=2)
+        w_off, w_idx = oracle_mod.alias_match_list(A, a_off, Ss, ss_off, K=2)
+        assert np.array_equal(off, w_off) and np.array_equal(idx, w_idx)
+    monkeypatch.delenv("MCX_LIST_TWO_PASS")
+    # the synthetic table both ways: same lists
+    P, N = 30000, 70000
+    A, a_off, a_mod = synth.alias_table(21, P)
+    S, s_off = synth.modalias_strings(21, P, N)
+    got = []
+    for two_pass in ("0", "1"):
+        monkeypatch.setenv("MCX_LIST_TWO_PASS", two_pass)
+        gpu_ctx.alias_table_load(A, a_off, a_mod)
+        got.append(gpu_ctx.alias_match_list(S, s_off))
+    monkeypatch.delenv("MCX_LIST_TWO_PASS")
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    o_off, o_idx = oracle_mod.alias_match_list(A, a_off, S[: s_off[300]], s_off[:301])
+    assert np.array_equal(got[0][0][:301], o_off) and np.array_equal(got[0][1][: o_off[300]], o_idx)
+
+
 @pytest.mark.parametrize("seed,P,N", [(2, 30000, 1000), (5, 777, 130), (6, 63, 1), (7, 5, 65), (8, 4096, 64)])
 def test_k1_synthetic_vs_oracle(gpu_ctx, oracle_mod, seed, P, N):
     """configs[1] (1000 x 30000, seed 2) and ragged shapes around the tile sizes"""
