@@ -52,9 +52,11 @@ void mcx_free_graph(mcx_ctx *ctx)
     (void)hipFree(ctx->d_rrowptr);
     (void)hipFree(ctx->d_rcol);
     (void)hipFree(ctx->d_part);
-    (void)hipFree(ctx->d_cu_part);
-    ctx->d_cu_part = nullptr;
-    ctx->n_cu_part = 0;
+    (void)hipFree(ctx->d_slices);
+    (void)hipFree(ctx->d_rpk);
+    ctx->d_slices = nullptr;
+    ctx->d_rpk = nullptr;
+    ctx->n_slices = 0;
     (void)hipFree(ctx->d_queue[0]);
     (void)hipFree(ctx->d_queue[1]);
     (void)hipFree(ctx->d_bfs);

@@ -59,9 +59,10 @@ struct mcx_ctx {
     uint32_t *d_part = nullptr;    /* row blocks of the reverse CSR (n_part + 1) */
     uint32_t n_part = 0;
     /* one slice of rows per CU for the variant of K2a that keeps the whole
-     * LOADED bitmap in LDS (n_cu_part = 0: the graph is too large for it) */
-    uint32_t *d_cu_part = nullptr;
-    uint32_t n_cu_part = 0, cu_rows_max = 0, cu_edges_max = 0;
+     * LOADED bitmap in LDS (n_slices = 0: the graph is too large for it) */
+    void *d_slices = nullptr;      /* n_slices records (r0, r1, e0, ne, first group of packed ids) */
+    uint32_t *d_rpk = nullptr;     /* the slices' holder ids, pk_bits (20 or 32) bits each, in the kernel's layout */
+    uint32_t n_slices = 0, pk_bits = 0, cu_rows_max = 0, cu_edges_max = 0;
     uint32_t *d_queue[2] = {nullptr, nullptr}; /* BFS frontiers, V entries each */
     uint32_t *d_bfs = nullptr;     /* BFS counters, then two hub lists of hub_cap entries, then two hub bitmaps */
     uint32_t n_hub[2] = {0, 0};    /* modules with a long adjacency list, per closure direction */

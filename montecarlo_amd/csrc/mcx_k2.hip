@@ -163,121 +163,224 @@ k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__
 
 /*
  * K2a with the LOADED bitmap in LDS: one block of 1024 threads per CU owns a
- * contiguous slice of rows with about E / #CU edges.  It copies the whole
- * bitmap (V/8 bytes) and its slice of rrowptr into LDS, streams its edges once,
- * coalesced, answering "is the holder loaded" from LDS (the per-edge gather
- * that bounds the other variant never leaves the CU), keeps the answers as one
- * bit per edge, and counts every row's set bits.  Used when bitmap + slice fit
- * the 160 KB of one workgroup.
+ * contiguous slice of rows with about E / #CU edges.  The holder ids of a
+ * slice are kept a second time in a form made for this kernel (built at graph
+ * load): 20 bits per id when V <= 2^20 (25 MB instead of 40 MB at 10^7 edges),
+ * 32 otherwise, cut into chunks of 32 ids and laid out so that piece q of the
+ * chunks of 64 consecutive lanes is one contiguous kilobyte:
+ *     group of 64 chunks (2048 ids)  ->  Q pieces x 64 lanes x 16 bytes.
+ * Everything the block needs is requested before anything is waited for: the
+ * whole bitmap (V/8 bytes, from L2), the row pointers and flag bytes of its
+ * rows, and the slice's ids, which stay in registers (two groups per wave: 65536
+ * ids per block without a second round; a slice has about 39000 at 10^7 edges
+ * and 256 CUs).  Then: bitmap and row pointers into LDS, one barrier, every lane
+ * answers "is this holder loaded" for its 32 ids from LDS and leaves the answers
+ * as one word of the edge-bit array, a second barrier, and a row's count is the
+ * number of set bits in its edge range.  Used when bitmap + slice fit the
+ * 160 KB of one workgroup.
  */
-#define K2L_THREADS 1024
-#define K2L_ROWS_CAP 4096u /* rows of one slice, at most */
-#define K2L_ROWS_PER_THREAD (K2L_ROWS_CAP / K2L_THREADS)
-__global__ void __launch_bounds__(K2L_THREADS)
-k2_flags_lds(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__ rcol,
-             const uint32_t *__restrict__ cu_part, const uint8_t *__restrict__ in_flags,
-             const uint32_t *__restrict__ loaded_bm, uint32_t W, uint32_t rows_max,
-             uint8_t *__restrict__ out_flags, uint32_t *__restrict__ refcnt)
+#ifndef K2P_EXP
+#define K2P_EXP 0u /* timing experiments (diagnostic builds only): 1 no bitmap copy, 2 no id loads, 4 no lookups, 8 no row pass */
+#endif
+#define K2P_THREADS 1024u
+#define K2P_WAVES (K2P_THREADS / 64u)
+#define K2P_ROWS_CAP 4096u /* rows of one slice, at most */
+#define K2P_ROWS_PER_THREAD (K2P_ROWS_CAP / K2P_THREADS)
+#define K2P_GROUP_IDS 2048u /* 64 lanes x 32 ids */
+
+struct k2p_slice_t {
+    uint32_t r0, r1; /* rows [r0, r1) */
+    uint32_t e0, ne; /* first entry of the reverse CSR, number of entries */
+    uint32_t g0;     /* first 2048-id group of the slice in the packed array */
+    uint32_t pad[3];
+};
+
+template <uint32_t BITS> struct k2p_fmt;
+template <> struct k2p_fmt<20u> {
+    static constexpr uint32_t Q = 5u; /* 16-byte pieces per chunk of 32 ids */
+    static constexpr uint32_t G = 2u; /* groups per wave held in registers */
+};
+template <> struct k2p_fmt<32u> {
+    static constexpr uint32_t Q = 8u;
+    static constexpr uint32_t G = 1u;
+};
+
+template <uint32_t BITS>
+__global__ void __launch_bounds__(K2P_THREADS)
+k2_flags_packed(const k2p_slice_t *__restrict__ slices, const uint32_t *__restrict__ rrowptr,
+                const uint4 *__restrict__ rpk, const uint8_t *__restrict__ in_flags,
+                const uint32_t *__restrict__ loaded_bm, uint32_t W, uint32_t rows_max, uint32_t ebits_words,
+                uint8_t *__restrict__ out_flags, uint32_t *__restrict__ refcnt)
 {
+    constexpr uint32_t Q = k2p_fmt<BITS>::Q, G = k2p_fmt<BITS>::G;
     extern __shared__ __attribute__((aligned(16))) uint32_t k2_lds[];
     const uint32_t W4 = (W + 3u) & ~3u;
-    uint32_t *bm = k2_lds;              /* W words, rounded up to whole 16-byte pieces */
-    uint32_t *rp = bm + W4;             /* rows_max + 1 */
-    uint32_t *ebits = rp + rows_max + 1u; /* edges_max / 32 + 2 */
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t r0 = cu_part[blockIdx.x], r1 = cu_part[blockIdx.x + 1];
-    const uint32_t R = r1 - r0;
-    const uint32_t e0 = rrowptr[r0], ne = rrowptr[r1] - e0;
-    /* a wave takes 1024 consecutive edges per step, 16 per lane, read with four
-     * 16-byte loads that are all in flight before the first answer is looked
-     * up: enough bytes under way per CU to cover the memory latency.  A lane's
-     * 16 answers are one half-word of the edge-bit array.  The loads of the
-     * first step are issued before the bitmap is copied, so that the two
-     * latencies overlap. */
-    const uint32_t wave = tid >> 6;
-    auto load_edges = [&](uint32_t first, uint32_t (&u)[16]) __attribute__((always_inline)) {
-        if (first + 16u <= ne) {
-            const uint4 *src = (const uint4 *)(rcol + e0 + first); /* 4-byte aligned */
+    uint32_t *bm = k2_lds;                /* W words, rounded up to whole 16-byte pieces */
+    uint32_t *rp = bm + W4;               /* rows_max + 1 */
+    uint32_t *ebits = rp + rows_max + 1u; /* one word per chunk of 32 entries */
+    uint32_t *pre = ebits + ebits_words + 1u; /* set bits in all words before this one; one more entry as well */
+    uint32_t *wtot = pre + ebits_words + 1u;  /* per wave and group of the round: set bits of its 64 words */
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const k2p_slice_t sl = slices[blockIdx.x];
+    const uint32_t R = sl.r1 - sl.r0, ne = sl.ne;
+    const uint32_t ngroups = (ne + K2P_GROUP_IDS - 1u) / K2P_GROUP_IDS;
+
+    /* the ids of round `round`: groups (round * G + g) * 16 + wave */
+    auto load_round = [&](uint32_t round, uint4 (&ev)[G][Q]) __attribute__((always_inline)) {
 #pragma unroll
-            for (uint32_t q = 0; q < 4u; ++q) {
-                const uint4 v = src[q];
-                u[4u * q] = v.x;
-                u[4u * q + 1u] = v.y;
-                u[4u * q + 2u] = v.z;
-                u[4u * q + 3u] = v.w;
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t grp = (round * G + g) * K2P_WAVES + wave;
+            if (grp < ngroups && !(K2P_EXP & 2u)) { /* the packed array holds whole groups: every lane may load */
+                const uint4 *src = rpk + ((size_t)sl.g0 + grp) * (Q * 64u) + lane;
+#pragma unroll
+                for (uint32_t q = 0; q < Q; ++q)
+                    ev[g][q] = src[q * 64u];
             }
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k)
-                u[k] = first + k < ne ? rcol[e0 + first + k] : 0xFFFFFFFFu;
         }
     };
-    uint32_t u[16];
-    load_edges(wave * 1024u + 16u * lane, u);
-    /* the flag bytes of this thread's rows (at most K2L_ROWS_PER_THREAD of them) */
-    uint32_t fl[K2L_ROWS_PER_THREAD];
+
+    /* 1. everything is requested before anything is waited for.  The bitmap and the row
+     * pointers go straight into LDS (loads that write LDS at a wave-wide base + lane x
+     * size: no registers, no store instruction), then the flag bytes and the ids. */
+    for (uint32_t i0 = wave * 64u; 4u * i0 < W4 && !(K2P_EXP & 1u); i0 += K2P_THREADS)
+        if (4u * (i0 + lane) < W4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(loaded_bm + 4u * (i0 + lane)),
+                                             (__attribute__((address_space(3))) void *)(bm + 4u * i0), 16, 0, 0);
 #pragma unroll
-    for (uint32_t k = 0; k < K2L_ROWS_PER_THREAD; ++k)
-        fl[k] = tid + K2L_THREADS * k < R ? in_flags[r0 + tid + K2L_THREADS * k] : 0u;
-    /* loaded_bm holds at least W4 words (it is V words long) */
-    for (uint32_t i = tid; 4u * i < W4; i += K2L_THREADS)
-        ((uint4 *)bm)[i] = ((const uint4 *)loaded_bm)[i];
-    for (uint32_t i = tid; i <= R; i += K2L_THREADS)
-        rp[i] = rrowptr[r0 + i];
-    __syncthreads();
-    uint16_t *ebits16 = (uint16_t *)ebits;
-    for (uint32_t base = wave * 1024u; base < ne; base += (K2L_THREADS / 64u) * 1024u) {
-        const uint32_t first = base + 16u * lane;
-        /* the next step's edges are requested before this step's are looked up */
-        const bool more = base + (K2L_THREADS / 64u) * 1024u < ne;
-        uint32_t un[16];
-        if (more)
-            load_edges(first + (K2L_THREADS / 64u) * 1024u, un);
-        uint32_t bits = 0;
+    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
+        const uint32_t i0 = wave * 64u + K2P_THREADS * k;
+        if (i0 + lane < R)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rrowptr + sl.r0 + i0 + lane),
+                                             (__attribute__((address_space(3))) void *)(rp + i0), 4, 0, 0);
+    }
+    uint32_t fl[K2P_ROWS_PER_THREAD];
 #pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k) {
-            const bool have = u[k] != 0xFFFFFFFFu;
-            const uint32_t w = bm[have ? u[k] >> 5 : 0u];
-            bits |= (have ? (w >> (u[k] & 31u)) & 1u : 0u) << k;
+    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
+        const uint32_t i = tid + K2P_THREADS * k;
+        fl[k] = in_flags[sl.r0 + (i < R ? i : R - 1u)]; /* a slice has at least one row */
+    }
+    uint4 ev[G][Q];
+    load_round(0u, ev);
+    if (tid == 0u)
+        rp[R] = sl.e0 + ne;
+    __syncthreads(); /* waits for the loads into LDS as well */
+
+    /* 3. a lane's 32 ids -> 32 answers -> one word of the edge-bit array, and beside it
+     * the number of set bits in all words before it (block-wide scan of the words'
+     * popcounts): a row's count is then a difference of two prefix values, whatever its
+     * length - a module held by ten thousand others costs what a leaf costs */
+    const uint32_t nchunks = (ne + 31u) >> 5;
+    uint32_t round_base = 0;
+    for (uint32_t round = 0;;) {
+        uint32_t cnt[G], incl[G];
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t grp = (round * G + g) * K2P_WAVES + wave;
+            const uint32_t chunk = grp * 64u + lane;
+            uint32_t bits = 0;
+            if (grp < ngroups && chunk < nchunks) {
+                uint32_t w[Q * 4u];
+#pragma unroll
+                for (uint32_t q = 0; q < Q; ++q) {
+                    w[4u * q] = ev[g][q].x;
+                    w[4u * q + 1u] = ev[g][q].y;
+                    w[4u * q + 2u] = ev[g][q].z;
+                    w[4u * q + 3u] = ev[g][q].w;
+                }
+#pragma unroll
+                for (uint32_t k0 = 0; k0 < 32u; k0 += 8u) {
+                    /* eight ids, eight LDS reads under way together, eight answers */
+                    uint32_t id[8], word[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j) {
+                        const uint32_t k = k0 + j;
+                        if constexpr (BITS == 32u) {
+                            id[j] = w[k];
+                        } else {
+                            const uint32_t pos = BITS * k, wi = pos >> 5, sh = pos & 31u;
+                            id[j] = (sh + BITS <= 32u ? w[wi] >> sh : __builtin_amdgcn_alignbit(w[wi + (sh + BITS > 32u ? 1u : 0u)], w[wi], sh)) &
+                                    ((1u << (BITS & 31u)) - 1u);
+                        }
+                        word[j] = (K2P_EXP & 4u) ? id[j] : bm[id[j] >> 5];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j)
+                        bits |= ((word[j] >> (id[j] & 31u)) & 1u) << (k0 + j);
+                }
+                const uint32_t left = ne - 32u * chunk; /* entries of this chunk that exist */
+                if (left < 32u)
+                    bits &= (1u << left) - 1u;
+                ebits[chunk] = bits;
+            }
+            cnt[g] = (uint32_t)__popc(bits);
+            uint32_t x = cnt[g];
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t o = __shfl_up(x, d, 64);
+                if (lane >= d)
+                    x += o;
+            }
+            incl[g] = x;
+            if (lane == 63u)
+                wtot[g * K2P_WAVES + wave] = x;
         }
-        if (first < ne + 16u)
-            ebits16[first >> 4] = (uint16_t)bits;
-        if (more) {
+        __syncthreads();
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k)
-                u[k] = un[k];
+        for (uint32_t g = 0; g < G; ++g) {
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < K2P_WAVES; ++k) {
+                const uint32_t t = wtot[g * K2P_WAVES + k];
+                total += t;
+                before += k < wave ? t : 0u;
+            }
+            const uint32_t chunk = ((round * G + g) * K2P_WAVES + wave) * 64u + lane;
+            if (chunk < nchunks)
+                pre[chunk] = round_base + before + incl[g] - cnt[g];
+            round_base += total;
         }
+        ++round;
+        if (round * G * K2P_WAVES >= ngroups)
+            break;
+        __syncthreads(); /* the wave totals are rewritten */
+        load_round(round, ev); /* slices of more than 65536 entries: a hub's row */
+    }
+    if (tid == 0u) {
+        pre[nchunks] = round_base; /* a row may end where the last word ends */
+        ebits[nchunks] = 0u;
     }
     __syncthreads();
+
+    /* 4. rows: loaded holders of a row = set bits before its end - set bits before its start */
+    auto before = [&](uint32_t x) __attribute__((always_inline)) {
+        return pre[x >> 5] + (uint32_t)__popc(ebits[x >> 5] & ((1u << (x & 31u)) - 1u));
+    };
+    uint32_t h[K2P_ROWS_PER_THREAD];
 #pragma unroll
-    for (uint32_t k = 0; k < K2L_ROWS_PER_THREAD; ++k) {
-        const uint32_t i = tid + K2L_THREADS * k;
-        if (i >= R)
+    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
+        const uint32_t i = tid + K2P_THREADS * k;
+        h[k] = 0;
+        if (i < R && !(K2P_EXP & 8u))
+            h[k] = before(rp[i + 1u] - sl.e0) - before(rp[i] - sl.e0);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
+        const uint32_t i = tid + K2P_THREADS * k;
+        if (i >= R || (K2P_EXP & 8u))
             break;
-        const uint32_t a = rp[i] - e0, b = rp[i + 1u] - e0;
-        uint32_t h = 0;
-        for (uint32_t w = a >> 5; 32u * w < b; ++w) {
-            uint32_t bits = ebits[w];
-            if (32u * w < a)
-                bits &= 0xFFFFFFFFu << (a & 31u);
-            if (32u * w + 32u > b)
-                bits &= 0xFFFFFFFFu >> ((32u - (b & 31u)) & 31u);
-            h += (uint32_t)__popc(bits);
-        }
-        const uint32_t v = r0 + i;
-        const uint32_t f = fl[k];
+        const uint32_t v = sl.r0 + i, f = fl[k];
         uint32_t o = 0;
         if (f & MCX_F_LOADED) {
-            if (h)
+            if (h[k])
                 o |= MCX_O_HAS_HOLDERS;
-            if ((f & MCX_F_BOUND) || h)
+            if ((f & MCX_F_BOUND) || h[k])
                 o |= MCX_O_IN_USE;
-            if ((f & MCX_F_SAFE) && !h)
+            if ((f & MCX_F_SAFE) && !h[k])
                 o |= MCX_O_ROOT;
         }
         out_flags[v] = (uint8_t)o;
         if (refcnt)
-            refcnt[v] = (f & MCX_F_LOADED) ? h + ((f & MCX_F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
+            refcnt[v] = (f & MCX_F_LOADED) ? h[k] + ((f & MCX_F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
     }
 }
 
@@ -794,6 +897,14 @@ static uint32_t *k2_static_bitmap(mcx_ctx *ctx)
 /* C ABI                                                                      */
 /* ------------------------------------------------------------------------- */
 
+/* dynamic LDS of k2_flags_packed: bitmap (whole 16-byte pieces), row pointers, edge bits */
+static size_t k2p_lds_bytes(const mcx_ctx *ctx)
+{
+    const size_t W4 = (((size_t)ctx->V + 31) / 32 + 3) & ~(size_t)3;
+    const size_t ebits_words = ((size_t)ctx->cu_edges_max + 31) / 32;
+    return 4 * (W4 + ctx->cu_rows_max + 1 + 2 * (ebits_words + 1) + 2 * K2P_WAVES + 8);
+}
+
 extern "C" {
 
 int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col, uint32_t V, uint32_t E)
@@ -873,32 +984,62 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
             order.clear();
         }
     }
-    /* slices for the LDS variant of K2a: one per CU, about E / #CU edges each */
-    std::vector<uint32_t> cu_part;
+    /* slices for the LDS variant of K2a: one per CU, about E / #CU edges each, and their
+     * holder ids once more, packed (see k2_flags_packed) */
+    std::vector<k2p_slice_t> slices;
+    std::vector<uint32_t> rpk;
     uint32_t cu_rows_max = 0, cu_edges_max = 0;
+    const uint32_t pk_bits = V <= (1u << 20) ? 20u : 32u;
     {
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n_cu <= 0)
             n_cu = 256;
         const uint64_t target = (uint64_t)E / (uint64_t)n_cu + 1;
-        const uint32_t rows_cap = K2L_ROWS_CAP; /* 16 KB of row pointers per slice */
-        cu_part.push_back(0);
+        uint64_t groups = 0;
         for (uint32_t r = 0; r < V;) {
             uint32_t end = r;
             uint64_t load = 0;
-            while (end < V && end - r < rows_cap &&
+            while (end < V && end - r < K2P_ROWS_CAP &&
                    (end == r || load + (rrow[end + 1] - rrow[end]) <= target)) {
                 load += rrow[end + 1] - rrow[end];
                 ++end;
             }
+            k2p_slice_t sl = {};
+            sl.r0 = r;
+            sl.r1 = end;
+            sl.e0 = rrow[r];
+            sl.ne = rrow[end] - rrow[r];
+            sl.g0 = (uint32_t)groups;
+            groups += (sl.ne + K2P_GROUP_IDS - 1u) / K2P_GROUP_IDS;
             cu_rows_max = std::max(cu_rows_max, end - r);
-            cu_edges_max = std::max(cu_edges_max, rrow[end] - rrow[r]);
-            cu_part.push_back(end);
+            cu_edges_max = std::max(cu_edges_max, sl.ne);
+            slices.push_back(sl);
             r = end;
         }
-        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 8);
-        if (V == 0 || lds > 160 * 1024 - 512)
-            cu_part.clear(); /* does not fit one workgroup: the row-block variant is used */
+        const size_t lds = 4 * ((size_t)(V + 31) / 32 + 4 + cu_rows_max + 1 + 2 * ((cu_edges_max + 31) / 32 + 1) +
+                                2 * K2P_WAVES + 8);
+        if (V == 0 || lds > 160 * 1024 - 512 || groups >= (1u << 22)) {
+            slices.clear(); /* does not fit one workgroup: the row-block variant is used */
+        } else {
+            const uint32_t Q = pk_bits == 20u ? k2p_fmt<20u>::Q : k2p_fmt<32u>::Q;
+            rpk.assign((size_t)groups * Q * 256u, 0u);
+            for (const k2p_slice_t &sl : slices)
+                for (uint32_t j = 0; j < sl.ne; ++j) {
+                    const uint32_t id = rcol[(size_t)sl.e0 + j];
+                    const uint32_t chunk = j >> 5, k = j & 31u, grp = chunk >> 6, ln = chunk & 63u;
+                    /* word t of the chunk sits in piece t / 4 of its lane */
+                    uint32_t *gbase = rpk.data() + ((size_t)sl.g0 + grp) * Q * 256u;
+                    auto word = [&](uint32_t t) -> uint32_t & { return gbase[((t >> 2) * 64u + ln) * 4u + (t & 3u)]; };
+                    if (pk_bits == 32u) {
+                        word(k) = id;
+                    } else {
+                        const uint32_t pos = 20u * k, t = pos >> 5, sh = pos & 31u;
+                        word(t) |= id << sh;
+                        if (sh > 12u)
+                            word(t + 1u) |= id >> (32u - sh);
+                    }
+                }
+        }
     }
     /* hubs of the closure search, per direction: bit v of words [d * W, (d + 1) * W) */
     const uint32_t W = (V + 31u) / 32u;
@@ -923,7 +1064,8 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         (rc = mcx_dev_upload(ctx, &ctx->d_rrowptr, rrow.data(), (size_t)V + 1)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_rcol, rcol.data(), (size_t)E)) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_part, part.data(), part.size())) != 0 ||
-        (rc = mcx_dev_upload(ctx, &ctx->d_cu_part, cu_part.data(), cu_part.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, (k2p_slice_t **)&ctx->d_slices, slices.data(), slices.size())) != 0 ||
+        (rc = mcx_dev_upload(ctx, &ctx->d_rpk, rpk.data(), rpk.size())) != 0 ||
         (rc = mcx_dev_upload(ctx, &ctx->d_lvl_order, order.data(), order.size())) != 0) {
         mcx_free_graph(ctx);
         return rc;
@@ -948,15 +1090,17 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     ctx->E = E;
     ctx->n_part = (uint32_t)part.size() - 1u;
     ctx->lvl_ptr = lvl_ptr;
-    ctx->n_cu_part = cu_part.empty() ? 0u : (uint32_t)cu_part.size() - 1u;
+    ctx->n_slices = (uint32_t)slices.size();
+    ctx->pk_bits = pk_bits;
     ctx->cu_rows_max = cu_rows_max;
     ctx->cu_edges_max = cu_edges_max;
-    if (ctx->n_cu_part) {
-        const size_t lds = 4 * ((size_t)(V + 31) / 32 + cu_rows_max + 1 + cu_edges_max / 32 + 8);
-        hipError_t ea = hipFuncSetAttribute((const void *)k2_flags_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds);
+    if (ctx->n_slices) {
+        const int lds = (int)k2p_lds_bytes(ctx);
+        hipError_t ea = hipFuncSetAttribute(pk_bits == 20u ? (const void *)k2_flags_packed<20u>
+                                                           : (const void *)k2_flags_packed<32u>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (ea != hipSuccess)
-            ctx->n_cu_part = 0;
+            ctx->n_slices = 0;
     }
     ctx->bfs_depth[0] = ctx->bfs_depth[1] = 0;
     ctx->graph_loaded = true;
@@ -970,11 +1114,18 @@ static int k2_enqueue_flags(mcx_ctx *ctx, const void *d_in_flags, void *d_out_fl
     const uint32_t W = (ctx->V + 31u) / 32u, W4 = (W + 3u) & ~3u;
     k2_loaded_bitmap<<<(W4 + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
         (const uint8_t *)d_in_flags, ctx->V, ((uintptr_t)d_in_flags & 15u) == 0u ? 1u : 0u, bm);
-    if (ctx->n_cu_part) {
-        const size_t lds = 4 * ((size_t)W + ctx->cu_rows_max + 1 + ctx->cu_edges_max / 32 + 8);
-        k2_flags_lds<<<ctx->n_cu_part, K2L_THREADS, lds, ctx->stream>>>(
-            ctx->d_rrowptr, ctx->d_rcol, ctx->d_cu_part, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
-            (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
+    if (ctx->n_slices) {
+        const size_t lds = k2p_lds_bytes(ctx);
+        const k2p_slice_t *slices = (const k2p_slice_t *)ctx->d_slices;
+        const uint4 *rpk = (const uint4 *)ctx->d_rpk;
+        if (ctx->pk_bits == 20u)
+            k2_flags_packed<20u><<<ctx->n_slices, K2P_THREADS, lds, ctx->stream>>>(
+                slices, ctx->d_rrowptr, rpk, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
+                (ctx->cu_edges_max + 31u) / 32u, (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
+        else
+            k2_flags_packed<32u><<<ctx->n_slices, K2P_THREADS, lds, ctx->stream>>>(
+                slices, ctx->d_rrowptr, rpk, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
+                (ctx->cu_edges_max + 31u) / 32u, (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
     } else {
         k2_flags_rows<<<ctx->n_part, K2_THREADS, 0, ctx->stream>>>(ctx->d_rrowptr, ctx->d_rcol, ctx->d_part,
                                                                   (const uint8_t *)d_in_flags, bm,

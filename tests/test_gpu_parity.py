@@ -680,6 +680,41 @@ def test_k2_graph_too_large_for_lds_bitmap(gpu_ctx, oracle_mod):
     check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
 
 
+def test_k2_wide_ids_and_long_rows(gpu_ctx, oracle_mod):
+    """The one-block-per-CU flag kernel in its other shapes: more than 2^20 modules (holder
+    ids kept as 32-bit words instead of 20-bit fields, bitmap still in LDS), and a module
+    held by 150000 others (a slice of one row whose ids do not fit the block's registers
+    at once: several rounds) beside rows of every small length."""
+    V = 1_100_000
+    rowptr, col = synth.dep_graph(9, V, 4)
+    flags = synth.dep_flags(9, rowptr, col)
+    seeds, _ = synth.seed_bitmap(9, flags, 4)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
+    # exactly 2^20 modules: the largest graph with 20-bit ids, and its last module is a holder
+    V = 1 << 20
+    rowptr, col = synth.dep_graph(10, V, 3)
+    flags = synth.dep_flags(10, rowptr, col)
+    flags[V - 1] |= 1
+    seeds, _ = synth.seed_bitmap(10, flags, 4)
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
+    rng = np.random.default_rng(5)
+    V = 200_000
+    holders = rng.choice(np.arange(1000, V), size=150_000, replace=False)
+    edges = {(int(u), 7) for u in holders}
+    for u in rng.integers(1000, V, size=300_000):
+        edges.add((int(u), int(rng.integers(0, 1000))))
+    e = np.array(sorted(edges), dtype=np.uint32)
+    rowptr = np.zeros(V + 1, dtype=np.uint32)
+    np.add.at(rowptr, e[:, 0].astype(np.int64) + 1, 1)
+    rowptr = np.cumsum(rowptr, dtype=np.uint64).astype(np.uint32)
+    col = np.ascontiguousarray(e[:, 1])
+    flags = np.where(rng.random(V) < 0.5, 5, 4).astype(np.uint8)
+    flags[7] = 7
+    seeds = np.zeros((V + 31) // 32, dtype=np.uint32)
+    seeds[0] = 1 << 7
+    check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
+
+
 def test_k1_normalize_dash_on_device(gpu_ctx, oracle_mod):
     """kmod's '-' -> '_' rule applied to the queried strings by the kernel: dashes in
     and outside brackets, unmatched brackets (unresolvable), bracket pairs that cross
