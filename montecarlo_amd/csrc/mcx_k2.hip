@@ -184,8 +184,10 @@ k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__
 #endif
 #define K2P_THREADS 1024u
 #define K2P_WAVES (K2P_THREADS / 64u)
-#define K2P_ROWS_CAP 4096u /* rows of one slice, at most */
-#define K2P_ROWS_PER_THREAD (K2P_ROWS_CAP / K2P_THREADS)
+#define K2P_ROWS_PRE 8u /* rows per thread whose pointers and flag bytes are requested at the start */
+#ifndef K2P_ROW_WEIGHT
+#define K2P_ROW_WEIGHT 6u /* a row costs about as much as this many holder entries */
+#endif
 #define K2P_GROUP_IDS 2048u /* 64 lanes x 32 ids */
 
 struct k2p_slice_t {
@@ -209,15 +211,14 @@ template <uint32_t BITS>
 __global__ void __launch_bounds__(K2P_THREADS)
 k2_flags_packed(const k2p_slice_t *__restrict__ slices, const uint32_t *__restrict__ rrowptr,
                 const uint4 *__restrict__ rpk, const uint8_t *__restrict__ in_flags,
-                const uint32_t *__restrict__ loaded_bm, uint32_t W, uint32_t rows_max, uint32_t ebits_words,
+                const uint32_t *__restrict__ loaded_bm, uint32_t W, uint32_t ebits_words,
                 uint8_t *__restrict__ out_flags, uint32_t *__restrict__ refcnt)
 {
     constexpr uint32_t Q = k2p_fmt<BITS>::Q, G = k2p_fmt<BITS>::G;
     extern __shared__ __attribute__((aligned(16))) uint32_t k2_lds[];
     const uint32_t W4 = (W + 3u) & ~3u;
-    uint32_t *bm = k2_lds;                /* W words, rounded up to whole 16-byte pieces */
-    uint32_t *rp = bm + W4;               /* rows_max + 1 */
-    uint32_t *ebits = rp + rows_max + 1u; /* one word per chunk of 32 entries */
+    uint32_t *bm = k2_lds;      /* W words, rounded up to whole 16-byte pieces */
+    uint32_t *ebits = bm + W4;  /* one word per chunk of 32 entries, and one more */
     uint32_t *pre = ebits + ebits_words + 1u; /* set bits in all words before this one; one more entry as well */
     uint32_t *wtot = pre + ebits_words + 1u;  /* per wave and group of the round: set bits of its 64 words */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -246,23 +247,18 @@ k2_flags_packed(const k2p_slice_t *__restrict__ slices, const uint32_t *__restri
         if (4u * (i0 + lane) < W4)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(loaded_bm + 4u * (i0 + lane)),
                                              (__attribute__((address_space(3))) void *)(bm + 4u * i0), 16, 0, 0);
+    /* a thread's rows: tid, tid + 1024, ...; the first K2P_ROWS_PRE of them are asked for now */
+    uint32_t fl[K2P_ROWS_PRE], ra[K2P_ROWS_PRE], rb[K2P_ROWS_PRE];
 #pragma unroll
-    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
-        const uint32_t i0 = wave * 64u + K2P_THREADS * k;
-        if (i0 + lane < R)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rrowptr + sl.r0 + i0 + lane),
-                                             (__attribute__((address_space(3))) void *)(rp + i0), 4, 0, 0);
-    }
-    uint32_t fl[K2P_ROWS_PER_THREAD];
-#pragma unroll
-    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
+    for (uint32_t k = 0; k < K2P_ROWS_PRE; ++k) {
         const uint32_t i = tid + K2P_THREADS * k;
-        fl[k] = in_flags[sl.r0 + (i < R ? i : R - 1u)]; /* a slice has at least one row */
+        const uint32_t v = sl.r0 + (i < R ? i : R - 1u); /* a slice has at least one row */
+        fl[k] = in_flags[v];
+        ra[k] = rrowptr[v];
+        rb[k] = rrowptr[v + 1u];
     }
     uint4 ev[G][Q];
     load_round(0u, ev);
-    if (tid == 0u)
-        rp[R] = sl.e0 + ne;
     __syncthreads(); /* waits for the loads into LDS as well */
 
     /* 3. a lane's 32 ids -> 32 answers -> one word of the edge-bit array, and beside it
@@ -355,32 +351,35 @@ k2_flags_packed(const k2p_slice_t *__restrict__ slices, const uint32_t *__restri
     auto before = [&](uint32_t x) __attribute__((always_inline)) {
         return pre[x >> 5] + (uint32_t)__popc(ebits[x >> 5] & ((1u << (x & 31u)) - 1u));
     };
-    uint32_t h[K2P_ROWS_PER_THREAD];
-#pragma unroll
-    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
-        const uint32_t i = tid + K2P_THREADS * k;
-        h[k] = 0;
-        if (i < R && !(K2P_EXP & 8u))
-            h[k] = before(rp[i + 1u] - sl.e0) - before(rp[i] - sl.e0);
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < K2P_ROWS_PER_THREAD; ++k) {
-        const uint32_t i = tid + K2P_THREADS * k;
-        if (i >= R || (K2P_EXP & 8u))
-            break;
-        const uint32_t v = sl.r0 + i, f = fl[k];
+    auto emit = [&](uint32_t v, uint32_t f, uint32_t h) __attribute__((always_inline)) {
         uint32_t o = 0;
         if (f & MCX_F_LOADED) {
-            if (h[k])
+            if (h)
                 o |= MCX_O_HAS_HOLDERS;
-            if ((f & MCX_F_BOUND) || h[k])
+            if ((f & MCX_F_BOUND) || h)
                 o |= MCX_O_IN_USE;
-            if ((f & MCX_F_SAFE) && !h[k])
+            if ((f & MCX_F_SAFE) && !h)
                 o |= MCX_O_ROOT;
         }
         out_flags[v] = (uint8_t)o;
         if (refcnt)
-            refcnt[v] = (f & MCX_F_LOADED) ? h[k] + ((f & MCX_F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
+            refcnt[v] = (f & MCX_F_LOADED) ? h + ((f & MCX_F_BOUND) ? 1u : 0u) : 0xFFFFFFFFu;
+    };
+    if (K2P_EXP & 8u)
+        return;
+    uint32_t h[K2P_ROWS_PRE];
+#pragma unroll
+    for (uint32_t k = 0; k < K2P_ROWS_PRE; ++k)
+        h[k] = tid + K2P_THREADS * k < R ? before(rb[k] - sl.e0) - before(ra[k] - sl.e0) : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < K2P_ROWS_PRE; ++k)
+        if (tid + K2P_THREADS * k < R)
+            emit(sl.r0 + tid + K2P_THREADS * k, fl[k], h[k]);
+    /* slices of more rows than that (modules nobody needs, in long runs) */
+    for (uint32_t i = tid + K2P_THREADS * K2P_ROWS_PRE; i < R; i += K2P_THREADS) {
+        const uint32_t v = sl.r0 + i;
+        const uint32_t f = in_flags[v], a = rrowptr[v], b = rrowptr[v + 1u];
+        emit(v, f, before(b - sl.e0) - before(a - sl.e0));
     }
 }
 
@@ -902,7 +901,7 @@ static size_t k2p_lds_bytes(const mcx_ctx *ctx)
 {
     const size_t W4 = (((size_t)ctx->V + 31) / 32 + 3) & ~(size_t)3;
     const size_t ebits_words = ((size_t)ctx->cu_edges_max + 31) / 32;
-    return 4 * (W4 + ctx->cu_rows_max + 1 + 2 * (ebits_words + 1) + 2 * K2P_WAVES + 8);
+    return 4 * (W4 + 2 * (ebits_words + 1) + 2 * K2P_WAVES + 8);
 }
 
 extern "C" {
@@ -994,30 +993,53 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n_cu <= 0)
             n_cu = 256;
-        const uint64_t target = (uint64_t)E / (uint64_t)n_cu + 1;
-        uint64_t groups = 0;
-        for (uint32_t r = 0; r < V;) {
-            uint32_t end = r;
-            uint64_t load = 0;
-            while (end < V && end - r < K2P_ROWS_CAP &&
-                   (end == r || load + (rrow[end + 1] - rrow[end]) <= target)) {
-                load += rrow[end + 1] - rrow[end];
-                ++end;
+        /* consecutive rows, cut so that no slice weighs more than `cap` (a row = its entries +
+         * K2P_ROW_WEIGHT; a row heavier than that is a slice of its own): the smallest cap
+         * that needs no more slices than there are CUs, so every block is resident at once */
+        auto cut = [&](uint64_t cap, std::vector<k2p_slice_t> *out) {
+            uint32_t n = 0;
+            uint64_t groups = 0;
+            for (uint32_t r = 0; r < V;) {
+                uint32_t end = r;
+                uint64_t load = 0;
+                while (end < V) {
+                    const uint64_t w = (uint64_t)(rrow[end + 1] - rrow[end]) + K2P_ROW_WEIGHT;
+                    if (end != r && load + w > cap)
+                        break;
+                    load += w;
+                    ++end;
+                }
+                if (out) {
+                    k2p_slice_t sl = {};
+                    sl.r0 = r;
+                    sl.r1 = end;
+                    sl.e0 = rrow[r];
+                    sl.ne = rrow[end] - rrow[r];
+                    sl.g0 = (uint32_t)groups;
+                    groups += (sl.ne + K2P_GROUP_IDS - 1u) / K2P_GROUP_IDS;
+                    out->push_back(sl);
+                }
+                ++n;
+                r = end;
             }
-            k2p_slice_t sl = {};
-            sl.r0 = r;
-            sl.r1 = end;
-            sl.e0 = rrow[r];
-            sl.ne = rrow[end] - rrow[r];
-            sl.g0 = (uint32_t)groups;
-            groups += (sl.ne + K2P_GROUP_IDS - 1u) / K2P_GROUP_IDS;
-            cu_rows_max = std::max(cu_rows_max, end - r);
-            cu_edges_max = std::max(cu_edges_max, sl.ne);
-            slices.push_back(sl);
-            r = end;
+            return n;
+        };
+        uint64_t lo = 1, hi = (uint64_t)E + (uint64_t)K2P_ROW_WEIGHT * V + 1;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (cut(mid, nullptr) <= (uint32_t)n_cu)
+                hi = mid;
+            else
+                lo = mid + 1;
         }
-        const size_t lds = 4 * ((size_t)(V + 31) / 32 + 4 + cu_rows_max + 1 + 2 * ((cu_edges_max + 31) / 32 + 1) +
-                                2 * K2P_WAVES + 8);
+        cut(lo, &slices);
+        uint64_t groups = 0;
+        for (const k2p_slice_t &sl : slices) {
+            groups += (sl.ne + K2P_GROUP_IDS - 1u) / K2P_GROUP_IDS;
+            cu_rows_max = std::max(cu_rows_max, sl.r1 - sl.r0);
+            cu_edges_max = std::max(cu_edges_max, sl.ne);
+        }
+        const size_t lds = 4 * ((size_t)(V + 31) / 32 + 4 + 2 * ((cu_edges_max + 31) / 32 + 1) + 2 * K2P_WAVES + 8);
         if (V == 0 || lds > 160 * 1024 - 512 || groups >= (1u << 22)) {
             slices.clear(); /* does not fit one workgroup: the row-block variant is used */
         } else {
@@ -1120,11 +1142,11 @@ static int k2_enqueue_flags(mcx_ctx *ctx, const void *d_in_flags, void *d_out_fl
         const uint4 *rpk = (const uint4 *)ctx->d_rpk;
         if (ctx->pk_bits == 20u)
             k2_flags_packed<20u><<<ctx->n_slices, K2P_THREADS, lds, ctx->stream>>>(
-                slices, ctx->d_rrowptr, rpk, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
+                slices, ctx->d_rrowptr, rpk, (const uint8_t *)d_in_flags, bm, W,
                 (ctx->cu_edges_max + 31u) / 32u, (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
         else
             k2_flags_packed<32u><<<ctx->n_slices, K2P_THREADS, lds, ctx->stream>>>(
-                slices, ctx->d_rrowptr, rpk, (const uint8_t *)d_in_flags, bm, W, ctx->cu_rows_max,
+                slices, ctx->d_rrowptr, rpk, (const uint8_t *)d_in_flags, bm, W,
                 (ctx->cu_edges_max + 31u) / 32u, (uint8_t *)d_out_flags, (uint32_t *)d_refcnt);
     } else {
         k2_flags_rows<<<ctx->n_part, K2_THREADS, 0, ctx->stream>>>(ctx->d_rrowptr, ctx->d_rcol, ctx->d_part,
