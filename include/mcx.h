@@ -464,8 +464,12 @@ int mcx_modtab_alias_arrays(mcx_modtab *t, const char **arena, const uint32_t **
                             const uint32_t **a_mod);
 /* dependency CSR over module ids, rows sorted.  direct = 0: the lists as the
  * file has them (transitive); direct = 1: without the entries another entry of
- * the same list already needs, i.e. the edges /sys/module/<m>/holders shows and
- * mcx_dep_graph_load wants. */
+ * the same list already needs (the transitive reduction), which is what
+ * mcx_dep_graph_load wants.  /sys/module/<m>/holders lists symbol-level users:
+ * a module that uses both B and C, where B uses C too, holds C there but has no
+ * edge to C here.  The flag bits of mcx_dep_flags are the same either way (a
+ * loaded holder implies the loaded chain below it); its reference counts and
+ * the closure's edges_scanned are lower bounds of what sysfs would count. */
 int mcx_modtab_dep_arrays(mcx_modtab *t, int direct, const uint32_t **rowptr, const uint32_t **col,
                           uint32_t *edges);
 const char *mcx_modtab_module_name(mcx_modtab *t, uint32_t id);   /* NULL if out of range */

@@ -106,7 +106,7 @@ void build_csr(mcx_modtab *t, bool direct)
     const uint32_t V = (uint32_t)t->names.size();
     t->rowptr.assign((size_t)V + 1, 0);
     t->col.clear();
-    std::vector<uint32_t> mark(V, 0xFFFFFFFFu);
+    std::vector<uint32_t> mark(V, 0xFFFFFFFFu), via(V, 0xFFFFFFFFu);
     for (uint32_t u = 0; u < V; ++u) {
         t->rowptr[u] = (uint32_t)t->col.size();
         std::vector<uint32_t> row;
@@ -117,24 +117,21 @@ void build_csr(mcx_modtab *t, bool direct)
                 row.push_back(d);
             }
         if (direct) {
-            /* modules.dep lists the closure: d is needed directly unless
-             * another listed module needs it too (it is then in that module's
-             * own list) */
+            /* modules.dep lists the closure: d is kept unless another listed module
+             * needs it too (it is then in that module's own list).  This is the
+             * transitive reduction of the file's lists: a module that uses symbols of
+             * both B and C, where B uses C as well, is a holder of C in sysfs but has
+             * no edge to C here.  A holder being loaded implies that everything between
+             * it and C is loaded, so has-holders, in-use and root come out the same;
+             * holder counts can be smaller than /sys/module/<m>/refcnt. */
+            for (uint32_t o : row)
+                for (uint32_t d : t->deps[o])
+                    if (d != o)
+                        via[d] = u;
             std::vector<uint32_t> keep;
-            for (uint32_t d : row) {
-                bool via = false;
-                for (uint32_t o : row) {
-                    if (o == d)
-                        continue;
-                    const auto &od = t->deps[o];
-                    if (std::find(od.begin(), od.end(), d) != od.end()) {
-                        via = true;
-                        break;
-                    }
-                }
-                if (!via)
+            for (uint32_t d : row)
+                if (via[d] != u)
                     keep.push_back(d);
-            }
             row.swap(keep);
         }
         std::sort(row.begin(), row.end());

@@ -85,3 +85,26 @@ def test_match_and_roots(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout.split() == ["e1000e", "rtw88_8821cu"]
     assert "1 loaded modules are not in the tables" in r.stderr
+
+
+def test_bench_usage():
+    r = run("bench", "-n", "0")
+    assert r.returncode == 1 and "bench [-d <dir>]" in r.stderr
+    r = run("bench", "extra-operand")
+    assert r.returncode == 1
+
+
+@pytest.mark.gpu
+def test_bench_subcommand(tmp_path):
+    """every string is made from a line of modules.alias, so every string resolves; the
+    JSON line carries the sizes of the tables it read"""
+    (tmp_path / "modules.alias").write_text(ALIAS_TEXT)
+    (tmp_path / "modules.dep").write_text(DEP_TEXT)
+    r = run("bench", "-d", str(tmp_path), "-n", "5000", "-r", "3")
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout)
+    n_alias = sum(1 for ln in ALIAS_TEXT.splitlines() if ln.startswith("alias "))
+    assert rec["patterns"] == n_alias and rec["strings"] == 5000 and rec["matched"] == 5000
+    assert rec["alias_match_ms"] > 0 and rec["dep_flags_ms"] > 0 and rec["modules"] > 0
+    r = run("bench", "-d", str(tmp_path / "nowhere"))
+    assert r.returncode == 2
