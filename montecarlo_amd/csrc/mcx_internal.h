@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -68,6 +70,7 @@ struct mcx_ctx {
     uint32_t n_hub[2] = {0, 0};    /* modules with a long adjacency list, per closure direction */
     uint32_t hub_cap = 0;
     uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */
+    uint32_t pinned_seq = 0;       /* last value a kernel was asked to leave in h_pinned[MCX_PINNED_SEQ_WORD] */
     uint32_t bfs_depth[2] = {0, 0}; /* per-level launches the last closure needed per direction behind its
                                        one-workgroup part (0: none, or no search yet) */
 
@@ -126,6 +129,34 @@ static inline int mcx_scratch(mcx_ctx *ctx, size_t bytes, void **out)
     }
     *out = ctx->d_fleet;
     return MCX_OK;
+}
+
+/* word of h_pinned that a read-back kernel stores last (a value that grows with every use) */
+#define MCX_PINNED_SEQ_WORD 40u
+
+/* Wait for a read-back kernel on the context's stream: spin on the sequence word it stores
+ * last, behind a system-scope fence, into pinned host memory (a few microseconds against
+ * about 25 for a stream synchronisation); after 200 us without it, synchronise the stream
+ * instead (which also reports a failed launch). */
+static inline int mcx_wait_seq(mcx_ctx *ctx, uint32_t want)
+{
+    volatile uint32_t *seq = ctx->h_pinned + MCX_PINNED_SEQ_WORD;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (*seq == want) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return 0;
+        }
+        if ((spins & 63u) == 63u &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200))
+            break;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*seq != want) {
+        ctx->err = "read-back kernel did not finish";
+        return MCX_E_HIP;
+    }
+    return 0;
 }
 
 static inline size_t up256(size_t x)

@@ -1232,7 +1232,7 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uin
  * device-to-host copies */
 __global__ void k2b_publish(const uint32_t *__restrict__ cnt, uint32_t first, uint32_t nwords,
                             uint32_t *__restrict__ h_sizes, unsigned long long *__restrict__ h_edges,
-                            uint32_t *__restrict__ h_small)
+                            uint32_t *__restrict__ h_small, uint32_t *h_seq, uint32_t seq)
 {
     const uint32_t i = threadIdx.x;
     if (i < nwords)
@@ -1242,6 +1242,11 @@ __global__ void k2b_publish(const uint32_t *__restrict__ cnt, uint32_t first, ui
         h_small[0] = cnt[K2B_W_SMALL_LEVELS];
         h_small[1] = cnt[K2B_W_HANDOVER];
     }
+    /* the sequence word goes last: the host spins on it instead of synchronising the stream */
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0)
+        __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* restart the window of per-level counters at level `base` (even, so that queue and hub list
@@ -1293,6 +1298,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&d_sizes, sizes, 0));
     unsigned long long *d_edges = (unsigned long long *)(d_sizes + 2 * K2B_BATCH);
     uint32_t *d_small = d_sizes + 2 * K2B_BATCH + 2;
+    uint32_t *d_seq = d_sizes + MCX_PINNED_SEQ_WORD;
     /* first the whole search in one workgroup, as far as it stays small (most closures of a
      * few modules end there: one launch, one look) */
     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags, (uint32_t *)d_out_bitmap,
@@ -1301,9 +1307,10 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
      * its first batch of levels is then enqueued without a look in between */
     const bool expect_handover = ctx->bfs_depth[direction] != 0u;
     if (!expect_handover) {
-        k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 0u, 2u, d_sizes, d_edges, d_small);
+        k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 0u, 2u, d_sizes, d_edges, d_small, d_seq, ++ctx->pinned_seq);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (mcx_wait_seq(ctx, ctx->pinned_seq))
+            return MCX_E_HIP;
     }
     uint32_t lv = 0;
     if (expect_handover || h_small[1] != 0u) {
@@ -1332,9 +1339,11 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                                                                       ctx->d_queue[(level + 1u) & 1u], st, level);
             }
             HIPCHK(ctx, hipGetLastError());
-            k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, d_sizes, d_edges, d_small);
+            k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, d_sizes, d_edges, d_small, d_seq,
+                                                   ++ctx->pinned_seq);
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (mcx_wait_seq(ctx, ctx->pinned_seq))
+                return MCX_E_HIP;
             for (uint32_t b = 0; b < batch; ++b) {
                 if (sizes[2u * b] == 0u && sizes[2u * b + 1u] == 0u) {
                     done = true;
