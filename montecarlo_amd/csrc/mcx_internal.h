@@ -65,8 +65,10 @@ struct mcx_ctx {
     void *d_slices = nullptr;      /* n_slices records (r0, r1, e0, ne, first group of packed ids) */
     uint32_t *d_rpk = nullptr;     /* the slices' holder ids, pk_bits (20 or 32) bits each, in the kernel's layout */
     uint32_t n_slices = 0, pk_bits = 0, cu_rows_max = 0, cu_edges_max = 0;
-    uint32_t *d_queue[2] = {nullptr, nullptr}; /* BFS frontiers, V entries each */
-    uint32_t *d_bfs = nullptr;     /* BFS counters, then two hub lists of hub_cap entries, then two hub bitmaps */
+    uint32_t *d_queue[2] = {nullptr, nullptr}; /* BFS frontiers, V (first entry, end) pairs each */
+    uint32_t *d_bfs = nullptr;     /* BFS counters, then two hub lists of hub_cap pairs, then the bitmap of loaded
+                                      modules not reached yet */
+    bool bfs_clean = false;        /* the counters are zero (the last search ended and cleared them) */
     uint32_t n_hub[2] = {0, 0};    /* modules with a long adjacency list, per closure direction */
     uint32_t hub_cap = 0;
     uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */

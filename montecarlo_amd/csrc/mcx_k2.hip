@@ -25,7 +25,9 @@
 #define K2_THREADS 256
 #define K2_ROWS 256u
 #define K2_EDGES 4096u
+#ifndef K2B_BLOCKS
 #define K2B_BLOCKS 1024u  /* grid of one BFS level; strides over the frontier */
+#endif
 #define K2B_BATCH 16u     /* most levels enqueued between two looks at the queue sizes */
 #define K2B_MAX_LEVELS 64u   /* window of per-level counters, reused by deeper searches */
 
@@ -388,10 +390,19 @@ k2_flags_packed(const k2p_slice_t *__restrict__ slices, const uint32_t *__restri
 /* ------------------------------------------------------------------------- */
 
 /*
- * Counters of a search: cnt[2 * level] = vertices in the frontier of that
- * level, cnt[2 * level + 1] = hubs of that level (vertices with more than
- * K2B_HUB adjacency entries, kept in a list of their own), all zeroed once per
- * call; then one 64-bit count of adjacency entries scanned.
+ * A frontier entry is a module's adjacency list, (first entry, end), not its
+ * number: whoever finds a module asks for its two row pointers in the same
+ * round trip as the claim, so that expanding it later starts at the list.
+ * `avail` has a bit per module: loaded and not reached yet (built by the seed
+ * kernel from the flag bytes); a claim is one atomic AND on it, the result
+ * bitmap gets its bit by an atomic OR nobody waits for.
+ *
+ * Counters of a search: cnt[2 * level] = entries in the frontier of that
+ * level, cnt[2 * level + 1] = hubs of that level (lists of more than K2B_HUB
+ * entries, kept in a list of their own), then one 64-bit count of adjacency
+ * entries scanned, the levels the one-workgroup kernel ran, and whether it
+ * handed over.  All zero between calls: the kernel that reports the end of a
+ * search clears them.
  */
 #define K2B_HUB 256u   /* longer adjacency lists are cut into pieces ...      */
 #define K2B_PIECE 512u /* ... of this many entries, dealt out over the grid  */
@@ -399,38 +410,64 @@ k2_flags_packed(const k2p_slice_t *__restrict__ slices, const uint32_t *__restri
 struct k2b_state_t {
     uint32_t *cnt;
     unsigned long long *edges;
-    const uint32_t *hubbits; /* bit v = v is a hub in this direction; nullptr = there is none */
-    uint32_t *hubq[2];       /* hubs of the even / odd levels */
+    uint32_t *avail;   /* bit v = v is loaded and not yet in the result */
+    uint2 *hubq[2];    /* hubs of the even / odd levels */
+};
+
+/* words of BFS state: the per-level counters, the edge count, and what the one-workgroup
+ * kernel leaves for the host: levels it ran, 1 if it handed over */
+#define K2B_STATE_WORDS (2u * (K2B_MAX_LEVELS + 1u) + 4u)
+#define K2B_W_EDGES (2u * (K2B_MAX_LEVELS + 1u))
+#define K2B_W_SMALL_LEVELS (K2B_W_EDGES + 2u)
+#define K2B_W_HANDOVER (K2B_W_EDGES + 3u)
+
+/* what a kernel that reports to the host writes, straight into pinned host memory */
+struct k2b_report_t {
+    uint32_t *sizes;            /* queue and hub list sizes of a run of levels */
+    unsigned long long *edges;
+    uint32_t *small;            /* levels of the one-workgroup kernel, handed over */
+    uint32_t *seq;              /* written last */
 };
 
 __global__ void __launch_bounds__(K2_THREADS)
-k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags, uint32_t V,
-         uint32_t *__restrict__ out, uint32_t *__restrict__ queue, k2b_state_t st)
+k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags, uint32_t aligned16, uint32_t V,
+         const uint32_t *__restrict__ rowptr, uint32_t *__restrict__ out, uint2 *__restrict__ queue, k2b_state_t st)
 {
-    /* one thread per bitmap word: the result word is the seed word restricted
-     * to loaded modules, written whole, so the bitmap needs no clearing */
+    /* one thread per bitmap word: LOADED bits of its 32 modules, the result word = the seed word
+     * restricted to loaded modules, written whole, so neither bitmap needs clearing */
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t W = (V + 31u) / 32u;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t keep = 0;
     if (w < W) {
-        uint32_t bits = seed[w];
-        while (bits) {
-            const uint32_t b = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1u;
-            const uint32_t v = 32u * w + b;
-            if (v < V && (in_flags[v] & MCX_F_LOADED))
-                keep |= 1u << b;
-        }
-        out[w] = keep;
-        if (st.hubbits && keep) {
-            uint32_t hub = keep & st.hubbits[w];
-            keep &= ~hub;
-            while (hub) { /* rare */
-                const uint32_t b = (uint32_t)__builtin_ctz(hub);
-                hub &= hub - 1u;
-                st.hubq[0][atomicAdd(&st.cnt[1], 1u)] = 32u * w + b;
+        const uint32_t v0 = 32u * w;
+        uint32_t loaded = 0;
+        if (aligned16 && v0 + 32u <= V) {
+            const uint4 *src = (const uint4 *)(in_flags + v0);
+            const uint4 lo = src[0], hi = src[1];
+            const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const uint32_t m = q[k] & 0x01010101u;
+                loaded |= (((m * 0x10204080u) >> 28) & 0xFu) << (4u * k);
             }
+        } else {
+            for (uint32_t k = 0; k < 32u && v0 + k < V; ++k)
+                loaded |= (uint32_t)(in_flags[v0 + k] & MCX_F_LOADED) << k;
+        }
+        keep = seed[w] & loaded;
+        out[w] = keep;
+        st.avail[w] = loaded & ~keep;
+    }
+    /* seeds with long lists go to the hub list (rare), the others to the queue */
+    uint32_t bits = keep;
+    while (bits) {
+        const uint32_t b = (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1u;
+        const uint32_t k0 = rowptr[32u * w + b], k1 = rowptr[32u * w + b + 1u];
+        if (k1 - k0 > K2B_HUB) {
+            keep &= ~(1u << b);
+            st.hubq[0][atomicAdd(&st.cnt[1], 1u)] = make_uint2(k0, k1);
         }
     }
     /* one queue reservation per wave: exclusive scan of the per-lane counts */
@@ -452,36 +489,36 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
     while (keep) {
         const uint32_t b = (uint32_t)__builtin_ctz(keep);
         keep &= keep - 1u;
-        queue[at++] = 32u * w + b;
+        queue[at++] = make_uint2(rowptr[32u * w + b], rowptr[32u * w + b + 1u]);
     }
 }
 
 /*
- * One level, edge-parallel.  A wave takes 64 frontier vertices, lays their
- * adjacency lists end to end (exclusive scan of the degrees, kept in LDS) and
- * then walks that concatenation 256 entries a step, four per lane: the owner
- * of entry j is found by bisection in the 64 scan values, the four neighbour
- * ids, their state bytes and their bitmap words are each requested together,
- * so a step costs three memory round trips whatever the degrees are.  New
- * vertices wait in a per-wave LDS buffer and are appended to the next frontier
+ * One level, edge-parallel.  A wave takes up to 64 frontier entries, lays their
+ * adjacency lists end to end (exclusive scan of the lengths, kept in LDS) and
+ * walks that concatenation 256 entries a step, four per lane: the owner of
+ * entry j is found by bisection in the 64 scan values; the four neighbour ids
+ * of a lane, then a look at their `avail` words, then the claims and row
+ * pointers of the open ones, are each requested together, so a step costs three
+ * memory round trips whatever the lengths are.  New
+ * entries wait in a per-wave LDS buffer and are appended to the next frontier
  * with one queue reservation per buffer.
  *
  * A hub (10^4 holders and more are common: the core modules everything needs)
- * would keep its wave busy long after the rest of the level is done.  Hubs are
- * known when the graph is loaded (a bitmap per direction); a newly found hub
- * goes to the hub list of the next level instead of its frontier, and every
- * level first walks its frontier and then the lists of its hubs cut into
- * pieces of K2B_PIECE entries, piece g going to wave g of the grid.
+ * would keep its wave busy long after the rest of the level is done.  A newly
+ * found hub goes to the hub list of the next level instead of its frontier,
+ * and every level first walks its frontier and then the lists of its hubs cut
+ * into pieces of K2B_PIECE entries, piece g going to wave g of the grid.
  */
 #define K2B_PER_LANE 4u
-#define K2B_BUF 1024u
+#define K2B_BUF 512u
 #ifndef K2B_GMIN
-#define K2B_GMIN 8u
+#define K2B_GMIN 16u
 #endif
 
-/* append a wave's buffered vertices to the next frontier: one reservation */
-__device__ __forceinline__ void k2b_flush(const uint32_t *buf, uint32_t n, uint32_t *__restrict__ next,
-                                          uint32_t *nsize, uint32_t lane)
+/* append a wave's buffered entries to the next frontier: one reservation */
+__device__ __forceinline__ void k2b_flush(const uint2 *buf, uint32_t n, uint2 *__restrict__ next, uint32_t *nsize,
+                                          uint32_t lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -498,50 +535,97 @@ __device__ __forceinline__ void k2b_flush(const uint32_t *buf, uint32_t n, uint3
 
 __global__ void __launch_bounds__(K2_THREADS)
 k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
-           const uint8_t *__restrict__ in_flags, const uint32_t *__restrict__ frontier,
-           uint32_t *__restrict__ out, uint32_t *__restrict__ next, k2b_state_t st, uint32_t level)
+           const uint2 *__restrict__ frontier, uint32_t *__restrict__ out, uint2 *__restrict__ next,
+           k2b_state_t st, uint32_t level, uint32_t sweep_waves)
 {
     __shared__ uint32_t pre[K2_THREADS / 64][65];
     __shared__ uint32_t beg[K2_THREADS / 64][64];
-    __shared__ uint32_t buf[K2_THREADS / 64][K2B_BUF];
+    __shared__ uint2 buf[K2_THREADS / 64][K2B_BUF];
+    __shared__ uint16_t hid[K2_THREADS / 64][256];
+    __shared__ uint32_t hmod[K2_THREADS / 64][256];
+    __shared__ uint32_t wn[K2_THREADS / 64 + 1];
+    __shared__ unsigned long long wscan[K2_THREADS / 64];
     uint32_t nbuf = 0; /* the same in all lanes of a wave */
     const uint32_t n = st.cnt[2u * level], nh = st.cnt[2u * level + 1u];
     if (n == 0u && nh == 0u)
         return;
     uint32_t *nsize = &st.cnt[2u * level + 2u], *nhub = &st.cnt[2u * level + 3u];
-    const uint32_t *hubbits = st.hubbits;
-    uint32_t *nexthubs = st.hubq[(level + 1u) & 1u];
+    uint32_t *avail = st.avail;
+    uint2 *nexthubs = st.hubq[(level + 1u) & 1u];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long scanned = 0;
 
-    /* the neighbours u[] of one step: state byte, bitmap word, claim, buffer */
+    /* the neighbours u[] of one step: claim, row pointers, result bit, buffer */
     auto visit = [&](const uint32_t (&u)[K2B_PER_LANE], const bool (&have)[K2B_PER_LANE])
                      __attribute__((always_inline)) {
-        uint32_t f[K2B_PER_LANE], w[K2B_PER_LANE], hb[K2B_PER_LANE];
+        bool cand[K2B_PER_LANE];
+        uint32_t old[K2B_PER_LANE], rb[K2B_PER_LANE], re[K2B_PER_LANE];
+        /* a look first: most neighbours of a level have been reached already, and the few
+         * modules everything needs would otherwise take an atomic from every lane that meets
+         * them.  A plain load: a word this CU's L1 still holds as it was shows bits that are
+         * gone, which costs a claim that fails, never a module. */
+        uint32_t w[K2B_PER_LANE];
 #pragma unroll
         for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
-            f[q] = have[q] ? in_flags[u[q]] : 0u;
+            w[q] = have[q] ? avail[u[q] >> 5] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
+            cand[q] = ((w[q] >> (u[q] & 31u)) & 1u) != 0u;
+        /* At the start of a level every wave that meets one of the modules everything needs
+         * still sees it open, and their claims on one word are served one after the other.  So
+         * a wave claims a module once: its open entries meet in a small hash table in LDS (the
+         * last writer of a slot owns it and leaves its module there; an entry that finds its
+         * own module under another owner is dropped). */
+        if (__ballot(cand[0] | cand[1] | cand[2] | cand[3])) {
+            uint32_t slot[K2B_PER_LANE];
+#pragma unroll
+            for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
+                slot[q] = (u[q] * 0x9E3779B1u) >> 24;
+                if (cand[q])
+                    hid[wave][slot[q]] = (uint16_t)(64u * q + lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            bool owner[K2B_PER_LANE];
+#pragma unroll
+            for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
+                owner[q] = cand[q] && hid[wave][slot[q]] == (uint16_t)(64u * q + lane);
+                if (owner[q])
+                    hmod[wave][slot[q]] = u[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
+                if (cand[q] && !owner[q] && hmod[wave][slot[q]] == u[q])
+                    cand[q] = false;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
-            const bool loaded = (f[q] & MCX_F_LOADED) != 0u;
-            w[q] = loaded ? out[u[q] >> 5] : 0xFFFFFFFFu;
-            hb[q] = (hubbits && loaded) ? hubbits[u[q] >> 5] : 0u;
+            old[q] = cand[q] ? atomicAnd(&avail[u[q] >> 5], ~(1u << (u[q] & 31u))) : 0u;
+            rb[q] = cand[q] ? rowptr[u[q]] : 0u;
+            re[q] = cand[q] ? rowptr[u[q] + 1u] : 0u;
         }
 #pragma unroll
         for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
             const uint32_t bit = 1u << (u[q] & 31u);
-            bool got = false;
-            if (!(w[q] & bit))
-                got = !(atomicOr(&out[u[q] >> 5], bit) & bit);
-            if (got && (hb[q] & bit)) { /* rare */
-                nexthubs[atomicAdd(nhub, 1u)] = u[q];
+            bool got = (old[q] & bit) != 0u;
+            if (got)
+                atomicOr(&out[u[q] >> 5], bit); /* nobody waits for it */
+            if (got && re[q] - rb[q] > K2B_HUB) { /* rare */
+                nexthubs[atomicAdd(nhub, 1u)] = make_uint2(rb[q], re[q]);
                 got = false;
             }
             const unsigned long long m = __ballot(got);
             if (m) {
                 if (got)
                     buf[wave][nbuf + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = u[q];
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                        make_uint2(rb[q], re[q]);
                 nbuf += (uint32_t)__popcll(m);
             }
         }
@@ -551,21 +635,21 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
         }
     };
 
-    /* the frontier, `grp` vertices per wave and round: 64 when there is enough
+    /* the frontier, `grp` entries per wave and round: 64 when there is enough
      * of it for the whole grid, fewer (down to K2B_GMIN) when there is not, so
      * that a short frontier of long lists still spreads over many waves */
-    const uint32_t nwaves_all = gridDim.x * (K2_THREADS / 64u);
+    const uint32_t nwaves_all = min(gridDim.x * (K2_THREADS / 64u), sweep_waves);
     uint32_t grp = 64u;
     while (grp > K2B_GMIN && (grp >> 1) * nwaves_all >= n)
         grp >>= 1;
     const uint32_t wave_all = blockIdx.x * (K2_THREADS / 64u) + wave;
-    for (uint32_t base = wave_all * grp; base < n; base += nwaves_all * grp) {
+    for (uint32_t base = wave_all < nwaves_all ? wave_all * grp : n; base < n; base += nwaves_all * grp) {
         const uint32_t t = base + lane;
         uint32_t k0 = 0, k1 = 0;
         if (lane < grp && t < n) {
-            const uint32_t v = frontier[t];
-            k0 = rowptr[v];
-            k1 = rowptr[v + 1];
+            const uint2 ent = frontier[t];
+            k0 = ent.x;
+            k1 = ent.y;
         }
         const uint32_t deg = k1 - k0;
         scanned += deg;
@@ -613,15 +697,15 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
      * end goes to wave g, counted from the far end of the grid (the near end
      * holds the frontier when that is short) */
     if (nh) {
-        const uint32_t *hubs = st.hubq[level & 1u];
+        const uint2 *hubs = st.hubq[level & 1u];
         const uint32_t nwaves = gridDim.x * (K2_THREADS / 64u);
         const uint32_t gwave = nwaves - 1u - (blockIdx.x * (K2_THREADS / 64u) + wave);
         for (uint32_t h0 = 0; h0 < nh; h0 += 64u) {
             uint32_t k0 = 0, k1 = 0;
             if (h0 + lane < nh) {
-                const uint32_t v = hubs[h0 + lane];
-                k0 = rowptr[v];
-                k1 = rowptr[v + 1];
+                const uint2 ent = hubs[h0 + lane];
+                k0 = ent.x;
+                k1 = ent.y;
             }
             if (gwave == 0u)
                 scanned += k1 - k0;
@@ -654,60 +738,81 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
             }
         }
     }
-    if (nbuf)
-        k2b_flush(buf[wave], nbuf, next, nsize, lane);
-    /* one add per wave */
+    /* what the waves still hold goes out with one queue reservation and one add to the entry
+     * count per block: a few thousand atomics on one word would take longer than the level
+     * (they are served one after the other, some 12 ns each) */
 #pragma unroll
     for (uint32_t d = 32; d >= 1; d >>= 1)
         scanned += __shfl_down(scanned, d, 64);
-    if (lane == 0 && scanned)
-        atomicAdd(st.edges, scanned);
+    if (lane == 0u) {
+        wn[wave] = nbuf;
+        wscan[wave] = scanned;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t tot = 0;
+        unsigned long long sc = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < K2_THREADS / 64u; ++k) {
+            const uint32_t c = wn[k];
+            wn[k] = tot;
+            tot += c;
+            sc += wscan[k];
+        }
+        wn[K2_THREADS / 64u] = tot ? atomicAdd(nsize, tot) : 0u;
+        if (sc)
+            atomicAdd(st.edges, sc);
+    }
+    __syncthreads();
+    const uint32_t at = wn[K2_THREADS / 64u] + wn[wave];
+    for (uint32_t i = lane; i < nbuf; i += 64u)
+        next[at + i] = buf[wave][i];
 }
 
-/* words of BFS state cleared per call: the per-level counters, the edge count, and what
- * the one-workgroup kernel leaves for the host: levels it expanded, 1 if it handed over */
-#define K2B_STATE_WORDS (2u * (K2B_MAX_LEVELS + 1u) + 4u)
-#define K2B_W_EDGES (2u * (K2B_MAX_LEVELS + 1u))
-#define K2B_W_SMALL_LEVELS (K2B_W_EDGES + 2u)
-#define K2B_W_HANDOVER (K2B_W_EDGES + 3u)
-
 /*
- * Closures of a few seeds have frontiers of a few hundred modules: a launch per level
- * is then all boundary and round-trip latency.  One workgroup of 1024 threads runs such
- * a search from start to end: the frontier lives in LDS (two queues of K2S_CAP
- * entries, each entry = module, start and end of its adjacency list), levels are
- * separated by __syncthreads(), the visited bitmap is the caller's output bitmap in
- * global memory (atomic OR).  A level is the concatenation of its modules'
- * adjacency lists, walked K2S_THREADS x K2S_PER entries a step; per entry the
- * neighbour's flag byte and its own row pointers are requested together (the
- * pointers are kept with the module if it turns out new, so the next level starts
- * without a round trip of its own), then one atomic OR decides who found it.
- * When a level outgrows the workgroup (more than K2S_CAP modules, or more than
- * K2S_LEVEL_MAX adjacency entries: a hub) the frontier goes to the global queue
- * and hub list in the form the per-level kernel expects, as its level 0.
+ * Closures of a few modules have frontiers of a few hundred entries for most of
+ * their levels: a launch per level is then all boundary and round-trip latency.
+ * One workgroup of 1024 threads runs such levels back to back: the frontier
+ * lives in LDS (two queues of K2S_CAP entries), levels are separated by
+ * __syncthreads().  A level is the concatenation of its adjacency lists, walked
+ * K2S_THREADS x K2S_PER entries a step; per entry the claim and the neighbour's
+ * row pointers are requested together.  The kernel is enqueued at level `level`
+ * of the counter window, in front of that level's own launch, and takes over
+ * when the frontier there is short and has no hub; it stops in front of a level
+ * that outgrows the workgroup (more than K2S_CAP entries, or more than
+ * K2S_LEVEL_MAX adjacency entries: faster on the whole chip) and leaves that
+ * frontier as level `level` again, queue and hub list in the form the per-level
+ * kernel expects.  So a search whose levels are small, then large, then small
+ * runs as: this kernel, a few per-level launches, this kernel.
+ * With `rep.seq` set it reports to the host when it returns (and clears the
+ * state if the search is over).
  */
 #define K2S_THREADS 1024u
 #define K2S_CAP 2048u
-#define K2S_PER 2u
-#define K2S_LEVEL_MAX 4096u /* two steps of the workgroup; more is faster on the whole chip */
+#define K2S_PER 4u
+#ifndef K2S_LEVEL_MAX
+#define K2S_LEVEL_MAX 4096u
+#endif
 
 __global__ void __launch_bounds__(K2S_THREADS)
-k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
-          const uint8_t *__restrict__ in_flags, uint32_t *__restrict__ out, uint32_t *__restrict__ queue0,
-          uint32_t *__restrict__ spill, k2b_state_t st)
+k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, uint32_t *__restrict__ out,
+          uint2 *__restrict__ queue, uint2 *__restrict__ spill, k2b_state_t st, uint32_t level, k2b_report_t rep,
+          uint32_t seq)
 {
-    __shared__ uint32_t qv[2][K2S_CAP], qb[2][K2S_CAP], qe[2][K2S_CAP]; /* module, list start, list end */
-    __shared__ uint32_t pre[K2S_CAP + 1u];                               /* exclusive sums of the list lengths */
+    __shared__ uint32_t qb[2][K2S_CAP], qe[2][K2S_CAP]; /* list start, list end */
+    __shared__ uint32_t pre[K2S_CAP + 1u];               /* exclusive sums of the list lengths */
     __shared__ uint32_t wsum[K2S_THREADS / 64u];
     __shared__ uint32_t nnext_sh, nq_sh, nh_sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t n = st.cnt[0];
-    const uint32_t nh0 = st.cnt[1];
+    uint32_t n = st.cnt[2u * level];
+    const uint32_t nh0 = st.cnt[2u * level + 1u];
+    uint32_t *avail = st.avail;
     unsigned long long scanned = 0; /* thread 0 keeps the sum */
     uint32_t levels = 0, cur = 0;
+    uint32_t left_q = n, left_h = nh0; /* what this level holds when the kernel returns (thread 0) */
 
-    /* write the frontier held in LDS queue `c` (first `nl` entries) plus `ns` spilled modules out
-     * as level 0 of the per-level kernel: hubs to the hub list, the rest to the queue */
+    /* leave the frontier held in LDS queue `c` (first `nl` entries) plus `ns` spilled entries
+     * as this level's: hubs to the hub list, the rest to the queue */
     auto hand_over = [&](uint32_t c, uint32_t nl, uint32_t ns) {
         if (tid == 0) {
             nq_sh = 0;
@@ -715,142 +820,152 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
         }
         __syncthreads();
         for (uint32_t i = tid; i < nl + ns; i += K2S_THREADS) {
-            const uint32_t v = i < nl ? qv[c][i] : spill[i - nl];
-            const bool hub = st.hubbits && ((st.hubbits[v >> 5] >> (v & 31u)) & 1u);
-            if (hub)
-                st.hubq[0][atomicAdd(&nh_sh, 1u)] = v;
+            const uint2 ent = i < nl ? make_uint2(qb[c][i], qe[c][i]) : spill[i - nl];
+            if (ent.y - ent.x > K2B_HUB)
+                st.hubq[level & 1u][atomicAdd(&nh_sh, 1u)] = ent;
             else
-                queue0[atomicAdd(&nq_sh, 1u)] = v;
+                queue[atomicAdd(&nq_sh, 1u)] = ent;
         }
         __syncthreads();
-        if (tid == 0) {
-            st.cnt[0] = nq_sh;
-            st.cnt[1] = nh_sh;
-            st.cnt[K2B_W_SMALL_LEVELS] = levels;
-            st.cnt[K2B_W_HANDOVER] = 1u;
-            if (scanned)
-                atomicAdd(st.edges, scanned);
-        }
+        left_q = nq_sh;
+        left_h = nh_sh;
     };
 
-    if (nh0 != 0u || n > K2S_CAP) {
-        /* seeds with a hub among them, or too many: nothing done here, the queue and the
-         * hub list stay as the seed kernel wrote them */
-        if (tid == 0)
-            st.cnt[K2B_W_HANDOVER] = 1u;
-        return;
+    const bool mine = nh0 == 0u && n != 0u && n <= K2S_CAP;
+    if (mine) {
+        for (uint32_t i = tid; i < n; i += K2S_THREADS) {
+            const uint2 ent = queue[i];
+            qb[0][i] = ent.x;
+            qe[0][i] = ent.y;
+        }
+        __syncthreads();
+        while (n != 0u) {
+            /* exclusive sums of the list lengths: K2S_CAP / K2S_THREADS = 2 entries per thread */
+            uint32_t d[K2S_CAP / K2S_THREADS], sum = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < K2S_CAP / K2S_THREADS; ++k) {
+                const uint32_t i = (K2S_CAP / K2S_THREADS) * tid + k;
+                d[k] = i < n ? qe[cur][i] - qb[cur][i] : 0u;
+                sum += d[k];
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (uint32_t s = 1; s < 64; s <<= 1) {
+                const uint32_t o = __shfl_up(incl, s, 64);
+                if (lane >= s)
+                    incl += o;
+            }
+            if (lane == 63u)
+                wsum[wave] = incl;
+            if (tid == 0)
+                nnext_sh = 0;
+            __syncthreads();
+            uint32_t at = incl - sum, total = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < K2S_THREADS / 64u; ++k) {
+                if (k < wave)
+                    at += wsum[k];
+                total += wsum[k];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < K2S_CAP / K2S_THREADS; ++k) {
+                const uint32_t i = (K2S_CAP / K2S_THREADS) * tid + k;
+                if (i <= n)
+                    pre[i] = at;
+                at += d[k];
+            }
+            __syncthreads();
+            if (total > K2S_LEVEL_MAX) {
+                hand_over(cur, n, 0u);
+                break;
+            }
+            ++levels;
+            scanned += total;
+            const uint32_t nxt = cur ^ 1u;
+            for (uint32_t j0 = 0; j0 < total; j0 += K2S_THREADS * K2S_PER) {
+                uint32_t u[K2S_PER], old[K2S_PER], b[K2S_PER], e[K2S_PER];
+                bool have[K2S_PER];
+#pragma unroll
+                for (uint32_t q = 0; q < K2S_PER; ++q) {
+                    const uint32_t j = j0 + K2S_THREADS * q + tid;
+                    have[q] = j < total;
+                    uint32_t lo = 0, hi = n; /* largest i with pre[i] <= j */
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (pre[mid] <= j)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    u[q] = have[q] ? col[qb[cur][lo] + (j - pre[lo])] : 0u;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < K2S_PER; ++q) /* a look first (see k2b_expand) */
+                    old[q] = have[q] ? __hip_atomic_load(&avail[u[q] >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < K2S_PER; ++q) {
+                    const bool open = ((old[q] >> (u[q] & 31u)) & 1u) != 0u;
+                    old[q] = open ? atomicAnd(&avail[u[q] >> 5], ~(1u << (u[q] & 31u))) : 0u;
+                    b[q] = open ? rowptr[u[q]] : 0u;
+                    e[q] = open ? rowptr[u[q] + 1u] : 0u;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < K2S_PER; ++q) {
+                    const uint32_t bit = 1u << (u[q] & 31u);
+                    if (!(old[q] & bit))
+                        continue;
+                    atomicOr(&out[u[q] >> 5], bit);
+                    const uint32_t at2 = atomicAdd(&nnext_sh, 1u);
+                    if (at2 < K2S_CAP) {
+                        qb[nxt][at2] = b[q];
+                        qe[nxt][at2] = e[q];
+                    } else {
+                        spill[at2 - K2S_CAP] = make_uint2(b[q], e[q]); /* the other level's queue: idle now */
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nn = nnext_sh;
+            if (nn > K2S_CAP) {
+                /* the spilled entries were written by this block: make them visible to its own reads */
+                __threadfence();
+                __syncthreads();
+                hand_over(nxt, K2S_CAP, nn - K2S_CAP);
+                n = nn;
+                break;
+            }
+            n = nn;
+            cur = nxt;
+            left_q = nn; /* zero when the search ends here */
+            left_h = 0;
+            __syncthreads(); /* nnext_sh is reset at the top of the next level */
+        }
     }
-    for (uint32_t i = tid; i < n; i += K2S_THREADS) {
-        const uint32_t v = queue0[i];
-        qv[0][i] = v;
-        qb[0][i] = rowptr[v];
-        qe[0][i] = rowptr[v + 1u];
+    /* record: this level's sizes as they stand now, the levels run here, the entries scanned */
+    __syncthreads();
+    if (tid == 0) {
+        st.cnt[2u * level] = left_q;
+        st.cnt[2u * level + 1u] = left_h;
+        const uint32_t small_levels = st.cnt[K2B_W_SMALL_LEVELS] + levels;
+        st.cnt[K2B_W_SMALL_LEVELS] = small_levels;
+        const uint32_t handed = (left_q != 0u || left_h != 0u) ? 1u : 0u;
+        st.cnt[K2B_W_HANDOVER] = handed;
+        unsigned long long edges = scanned ? atomicAdd(st.edges, scanned) + scanned : *st.edges;
+        if (seq) {
+            rep.sizes[0] = left_q;
+            rep.sizes[1] = left_h;
+            *rep.edges = edges;
+            rep.small[0] = small_levels;
+            rep.small[1] = handed;
+            __threadfence_system();
+            __hip_atomic_store(rep.seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        wsum[0] = (seq && !handed) ? 1u : 0u; /* the search is over and the host has been told: clear the state */
     }
     __syncthreads();
-    while (n != 0u) {
-        /* exclusive sums of the list lengths: K2S_CAP / K2S_THREADS = 4 modules per thread */
-        uint32_t d[K2S_CAP / K2S_THREADS], mine = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < K2S_CAP / K2S_THREADS; ++k) {
-            const uint32_t i = (K2S_CAP / K2S_THREADS) * tid + k;
-            d[k] = i < n ? qe[cur][i] - qb[cur][i] : 0u;
-            mine += d[k];
-        }
-        uint32_t incl = mine;
-#pragma unroll
-        for (uint32_t s = 1; s < 64; s <<= 1) {
-            const uint32_t o = __shfl_up(incl, s, 64);
-            if (lane >= s)
-                incl += o;
-        }
-        if (lane == 63u)
-            wsum[wave] = incl;
-        if (tid == 0)
-            nnext_sh = 0;
-        __syncthreads();
-        uint32_t at = incl - mine, total = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < K2S_THREADS / 64u; ++k) {
-            if (k < wave)
-                at += wsum[k];
-            total += wsum[k];
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < K2S_CAP / K2S_THREADS; ++k) {
-            const uint32_t i = (K2S_CAP / K2S_THREADS) * tid + k;
-            if (i <= n)
-                pre[i] = at;
-            at += d[k];
-        }
-        __syncthreads();
-        if (total > K2S_LEVEL_MAX) {
-            hand_over(cur, n, 0u);
-            return;
-        }
-        ++levels;
-        scanned += total;
-        const uint32_t nxt = cur ^ 1u;
-        for (uint32_t j0 = 0; j0 < total; j0 += K2S_THREADS * K2S_PER) {
-            uint32_t u[K2S_PER], f[K2S_PER], b[K2S_PER], e[K2S_PER];
-            bool have[K2S_PER];
-#pragma unroll
-            for (uint32_t q = 0; q < K2S_PER; ++q) {
-                const uint32_t j = j0 + K2S_THREADS * q + tid;
-                have[q] = j < total;
-                uint32_t lo = 0, hi = n; /* largest i with pre[i] <= j */
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (pre[mid] <= j)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                u[q] = have[q] ? col[qb[cur][lo] + (j - pre[lo])] : 0u;
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < K2S_PER; ++q) {
-                f[q] = have[q] ? in_flags[u[q]] : 0u;
-                b[q] = have[q] ? rowptr[u[q]] : 0u;
-                e[q] = have[q] ? rowptr[u[q] + 1u] : 0u;
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < K2S_PER; ++q) {
-                if (!(f[q] & MCX_F_LOADED))
-                    continue;
-                const uint32_t bit = 1u << (u[q] & 31u);
-                if (atomicOr(&out[u[q] >> 5], bit) & bit)
-                    continue;
-                const uint32_t at2 = atomicAdd(&nnext_sh, 1u);
-                if (at2 < K2S_CAP) {
-                    qv[nxt][at2] = u[q];
-                    qb[nxt][at2] = b[q];
-                    qe[nxt][at2] = e[q];
-                } else {
-                    spill[at2 - K2S_CAP] = u[q]; /* the current level's global queue: its content is in LDS */
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t nn = nnext_sh;
-        if (nn > K2S_CAP) {
-            /* the spilled modules were written by this block: make them visible to its own reads */
-            __threadfence();
-            __syncthreads();
-            hand_over(nxt, K2S_CAP, nn - K2S_CAP);
-            return;
-        }
-        n = nn;
-        cur = nxt;
-        __syncthreads(); /* nnext_sh is reset at the top of the next level */
-    }
-    if (tid == 0) {
-        st.cnt[0] = 0u;
-        st.cnt[1] = 0u;
-        st.cnt[K2B_W_SMALL_LEVELS] = levels;
-        st.cnt[K2B_W_HANDOVER] = 0u;
-        if (scanned)
-            atomicAdd(st.edges, scanned);
-    }
+    if (wsum[0])
+        for (uint32_t i = tid; i < K2B_STATE_WORDS; i += K2S_THREADS)
+            st.cnt[i] = 0u;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1063,19 +1178,14 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
                 }
         }
     }
-    /* hubs of the closure search, per direction: bit v of words [d * W, (d + 1) * W) */
+    /* modules with long lists, per direction: room for the hub lists of the closure search */
     const uint32_t W = (V + 31u) / 32u;
-    std::vector<uint32_t> hubbits((size_t)2 * W + 1, 0);
     uint32_t n_hub[2] = {0, 0};
     for (uint32_t v = 0; v < V; ++v) {
-        if (rrow[(size_t)v + 1] - rrow[v] > K2B_HUB) {
-            hubbits[v >> 5] |= 1u << (v & 31u);
+        if (rrow[(size_t)v + 1] - rrow[v] > K2B_HUB)
             ++n_hub[MCX_CLOSURE_HOLDERS];
-        }
-        if (rowptr[v + 1] - rowptr[v] > K2B_HUB) {
-            hubbits[(size_t)W + (v >> 5)] |= 1u << (v & 31u);
+        if (rowptr[v + 1] - rowptr[v] > K2B_HUB)
             ++n_hub[MCX_CLOSURE_DEPS];
-        }
     }
     const uint32_t hub_cap = std::max(n_hub[0], n_hub[1]);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1092,18 +1202,19 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
         mcx_free_graph(ctx);
         return rc;
     }
-    size_t vb = 4 * ((size_t)V > 4 ? V : 4); /* the bitmap copy of K2a reads whole 16-byte pieces */
+    /* two frontier queues of V (first entry, end) pairs (the first doubles as K2a's LOADED
+     * bitmap, whose copy reads whole 16-byte pieces); BFS state, the two hub lists, the bitmap
+     * of loaded modules not reached yet */
+    size_t vb = 8 * ((size_t)V > 4 ? V : 4);
     if (hipMalloc((void **)&ctx->d_queue[0], vb) != hipSuccess ||
         hipMalloc((void **)&ctx->d_queue[1], vb) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_bfs, 4 * ((size_t)K2B_STATE_WORDS + 2 * (size_t)hub_cap + 2 * (size_t)W + 1)) !=
+        hipMalloc((void **)&ctx->d_bfs, 4 * ((size_t)K2B_STATE_WORDS + 4 * (size_t)hub_cap + (size_t)W + 4)) !=
             hipSuccess) {
         mcx_free_graph(ctx);
         ctx->err = "hipMalloc of graph scratch failed";
         return MCX_E_NOMEM;
     }
-    /* BFS state, the two hub lists, the two hub bitmaps */
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_bfs + K2B_STATE_WORDS + 2 * (size_t)hub_cap, hubbits.data(),
-                               4 * ((size_t)2 * W + 1), hipMemcpyHostToDevice, ctx->stream));
+    ctx->bfs_clean = false;
     ctx->n_hub[0] = n_hub[0];
     ctx->n_hub[1] = n_hub[1];
     ctx->hub_cap = hub_cap;
@@ -1229,24 +1340,35 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uin
 
 /* the queue sizes of a batch of levels, the edge count and the record of the one-workgroup
  * kernel, written straight into pinned host memory: one small launch instead of
- * device-to-host copies */
-__global__ void k2b_publish(const uint32_t *__restrict__ cnt, uint32_t first, uint32_t nwords,
-                            uint32_t *__restrict__ h_sizes, unsigned long long *__restrict__ h_edges,
-                            uint32_t *__restrict__ h_small, uint32_t *h_seq, uint32_t seq)
+ * device-to-host copies.  A batch with an empty level in it was the last one: the state
+ * is then cleared for the next call. */
+__global__ void k2b_publish(uint32_t *__restrict__ cnt, uint32_t first, uint32_t nwords, k2b_report_t rep, uint32_t seq)
 {
+    __shared__ uint32_t ended;
     const uint32_t i = threadIdx.x;
-    if (i < nwords)
-        h_sizes[i] = cnt[first + i];
+    if (i == 0)
+        ended = 0u;
+    __syncthreads();
+    if (i < nwords) {
+        const uint32_t x = cnt[first + i];
+        rep.sizes[i] = x;
+        /* even words are queue sizes, the odd word behind each the hub count of that level */
+        if (!(i & 1u) && x == 0u && cnt[first + i + 1u] == 0u)
+            ended = 1u;
+    }
     if (i == 0) {
-        *h_edges = *(const unsigned long long *)(cnt + K2B_W_EDGES);
-        h_small[0] = cnt[K2B_W_SMALL_LEVELS];
-        h_small[1] = cnt[K2B_W_HANDOVER];
+        *rep.edges = *(const unsigned long long *)(cnt + K2B_W_EDGES);
+        rep.small[0] = cnt[K2B_W_SMALL_LEVELS];
+        rep.small[1] = cnt[K2B_W_HANDOVER];
     }
     /* the sequence word goes last: the host spins on it instead of synchronising the stream */
     __threadfence_system();
     __syncthreads();
     if (i == 0)
-        __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rep.seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ended)
+        for (uint32_t k = i; k < K2B_STATE_WORDS; k += blockDim.x)
+            cnt[k] = 0u;
 }
 
 /* restart the window of per-level counters at level `base` (even, so that queue and hub list
@@ -1281,51 +1403,65 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     const uint32_t *rp = direction == MCX_CLOSURE_HOLDERS ? ctx->d_rrowptr : ctx->d_rowptr;
     const uint32_t *cl = direction == MCX_CLOSURE_HOLDERS ? ctx->d_rcol : ctx->d_col;
     const uint32_t W = (V + 31) / 32;
+    uint2 *queue[2] = {(uint2 *)ctx->d_queue[0], (uint2 *)ctx->d_queue[1]};
     k2b_state_t st;
     st.cnt = ctx->d_bfs;
     st.edges = (unsigned long long *)(ctx->d_bfs + K2B_W_EDGES); /* 8-byte aligned */
-    st.hubq[0] = ctx->d_bfs + K2B_STATE_WORDS;
+    st.hubq[0] = (uint2 *)(ctx->d_bfs + K2B_STATE_WORDS);
     st.hubq[1] = st.hubq[0] + ctx->hub_cap;
-    st.hubbits = ctx->n_hub[direction] ? st.hubq[1] + ctx->hub_cap + (size_t)direction * W : nullptr;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_bfs, 0, 4 * (size_t)K2B_STATE_WORDS, ctx->stream));
+    st.avail = (uint32_t *)(st.hubq[1] + ctx->hub_cap);
+    /* the kernel that reports the end of a search clears the state; a call that failed on the
+     * way, or the first one on this graph, clears it here */
+    if (!ctx->bfs_clean)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_bfs, 0, 4 * (size_t)K2B_STATE_WORDS, ctx->stream));
+    ctx->bfs_clean = false;
     k2b_seed<<<(W + K2_THREADS - 1) / K2_THREADS, K2_THREADS, 0, ctx->stream>>>(
-        (const uint32_t *)d_seed_bitmap, (const uint8_t *)d_in_flags, V, (uint32_t *)d_out_bitmap,
-        ctx->d_queue[0], st);
+        (const uint32_t *)d_seed_bitmap, (const uint8_t *)d_in_flags, ((uintptr_t)d_in_flags & 15u) == 0u ? 1u : 0u, V,
+        rp, (uint32_t *)d_out_bitmap, queue[0], st);
     uint32_t *sizes = ctx->h_pinned;                                  /* 2 * K2B_BATCH words */
     unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 2 * K2B_BATCH);
     uint32_t *h_small = ctx->h_pinned + 2 * K2B_BATCH + 2;            /* levels, handed over */
     uint32_t *d_sizes = nullptr; /* the same pinned memory as the device addresses it */
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&d_sizes, sizes, 0));
-    unsigned long long *d_edges = (unsigned long long *)(d_sizes + 2 * K2B_BATCH);
-    uint32_t *d_small = d_sizes + 2 * K2B_BATCH + 2;
-    uint32_t *d_seq = d_sizes + MCX_PINNED_SEQ_WORD;
-    /* first the whole search in one workgroup, as far as it stays small (most closures of a
-     * few modules end there: one launch, one look) */
-    k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags, (uint32_t *)d_out_bitmap,
-                                                  ctx->d_queue[0], ctx->d_queue[1], st);
-    /* a search that handed over last time in this direction will most likely do so again:
-     * its first batch of levels is then enqueued without a look in between */
+    k2b_report_t rep;
+    rep.sizes = d_sizes;
+    rep.edges = (unsigned long long *)(d_sizes + 2 * K2B_BATCH);
+    rep.small = d_sizes + 2 * K2B_BATCH + 2;
+    rep.seq = d_sizes + MCX_PINNED_SEQ_WORD;
+    /* first the one-workgroup kernel, as far as the levels stay small (most closures of a few
+     * modules end there: one launch, which also reports).  A search that needed per-level
+     * launches last time in this direction will most likely do so again: its first batch is
+     * then enqueued without a look in between. */
     const bool expect_handover = ctx->bfs_depth[direction] != 0u;
-    if (!expect_handover) {
-        k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 0u, 2u, d_sizes, d_edges, d_small, d_seq, ++ctx->pinned_seq);
-        HIPCHK(ctx, hipGetLastError());
-        if (mcx_wait_seq(ctx, ctx->pinned_seq))
-            return MCX_E_HIP;
-    }
+    const uint32_t seq0 = expect_handover ? 0u : ++ctx->pinned_seq;
+    k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[0], queue[1], st, 0u, rep, seq0);
+    HIPCHK(ctx, hipGetLastError());
+    if (!expect_handover && mcx_wait_seq(ctx, seq0))
+        return MCX_E_HIP;
     uint32_t lv = 0;
     if (expect_handover || h_small[1] != 0u) {
-        /* handed over: a launch per level from here.  Levels are enqueued a batch at a time; a
-         * level whose frontier is empty returns at once (1.7 us), and the queue sizes of a batch
-         * tell where the search ended; looking costs a stream synchronisation.  Searches over
-         * one graph tend to be equally deep, so a batch is as long as the last search in this
-         * direction was, plus two (even, so that the counter window can be restarted at a batch
-         * boundary): a shallow search does not pay for a dozen empty levels and a deep one looks
-         * once.  The window of K2B_MAX_LEVELS per-level counters is reused as often as needed. */
+        /* a launch per level from here, with the one-workgroup kernel in front of every second
+         * level (it returns at once while the frontier is large, and takes the rest of the
+         * search when it has become short again).  Levels are enqueued a batch at a time; a
+         * level whose frontier is empty returns at once, and the queue sizes of a batch tell
+         * where the search ended.  Searches over one graph tend to be equally deep, so a
+         * batch is as long as the last search in this direction was, plus two (even, so that
+         * the counter window can be restarted at a batch boundary).  The window of
+         * K2B_MAX_LEVELS per-level counters is reused as often as needed. */
         const uint32_t hint = ctx->bfs_depth[direction];
         uint32_t batch = hint ? (hint + 2u < 4u ? 4u : (hint + 2u > K2B_BATCH ? K2B_BATCH : hint + 2u)) : 8u;
         batch = (batch + 1u) & ~1u;
         uint32_t base = 0; /* level of the counter window the next batch starts at */
         bool done = false;
+        k2b_report_t none = {};
+        /* Towards the dependencies every list leads to the same few modules everything needs:
+         * at the start of a level each wave still sees them open and claims them, and claims
+         * on one cache line are served one after the other - the first step of such a level
+         * takes longer the more waves take it at once (10^5 seeds: 504 us with 4096 waves,
+         * 171 with 1024).  So there a quarter of the grid sweeps the frontier; all of it
+         * still shares the hubs' lists. */
+        const uint32_t sweep_waves = direction == MCX_CLOSURE_DEPS ? K2B_BLOCKS * (K2_THREADS / 64u) / 4u
+                                                                   : K2B_BLOCKS * (K2_THREADS / 64u);
         while (!done) {
             if (base + batch + 1u > K2B_MAX_LEVELS) {
                 k2b_rewind<<<1, 256, 0, ctx->stream>>>(st.cnt, base);
@@ -1333,14 +1469,15 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
             }
             for (uint32_t b = 0; b < batch; ++b) {
                 const uint32_t level = base + b;
-                k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, (const uint8_t *)d_in_flags,
-                                                                      ctx->d_queue[level & 1u],
+                if (b != 0u && !(b & 1u))
+                    k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[level & 1u],
+                                                                  queue[(level + 1u) & 1u], st, level, none, 0u);
+                k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, queue[level & 1u],
                                                                       (uint32_t *)d_out_bitmap,
-                                                                      ctx->d_queue[(level + 1u) & 1u], st, level);
+                                                                      queue[(level + 1u) & 1u], st, level, sweep_waves);
             }
             HIPCHK(ctx, hipGetLastError());
-            k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, d_sizes, d_edges, d_small, d_seq,
-                                                   ++ctx->pinned_seq);
+            k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, rep, ++ctx->pinned_seq);
             HIPCHK(ctx, hipGetLastError());
             if (mcx_wait_seq(ctx, ctx->pinned_seq))
                 return MCX_E_HIP;
@@ -1353,9 +1490,10 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
             }
             base += batch;
         }
-        /* 0: the one-workgroup kernel did it all (its levels then all read as empty here) */
-        ctx->bfs_depth[direction] = h_small[1] ? (lv > K2B_BATCH ? K2B_BATCH : (lv ? lv : 1u)) : 0u;
+        /* 0: the one-workgroup kernel did it all */
+        ctx->bfs_depth[direction] = lv > K2B_BATCH ? K2B_BATCH : lv;
     }
+    ctx->bfs_clean = true;
     if (edges_scanned)
         *edges_scanned = *h_edges;
     if (levels)
