@@ -544,6 +544,8 @@ def bench_k2(ctx, synth, args, with_cpu=False):
             "achieved_GBs": alg_flags / (flags_ms / 1e3) / 1e9,
             "frac_of_hbm_peak": alg_flags / (flags_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
             "traffic": measured_traffic_k2(alg_flags),
+            "note": "algorithmic bytes count 4 bytes per holder id; the kernel streams a second copy of the "
+                    "ids kept at 20 bits each (V <= 2^20), so its HBM traffic is below them",
         },
     }
     # closure: 16 seeds (what an operator asks for one device's drivers: latency bound) and the
