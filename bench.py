@@ -65,7 +65,7 @@ def measured_traffic(N, P):
     """HBM bytes per K1 launch from rocprofv3 PMC passes of this same command
     (FETCH_SIZE doubled, as gfx950 reports half of a streamed read, plus
     WRITE_SIZE; both in KiB), kept in profiles/k1_traffic.json by
-    scripts/pmc_traffic.py.  None when no measurement of this workload is on file."""
+    scripts/profile_digest.py.  None when no measurement of this workload is on file."""
     path = os.path.join(ROOT, "profiles", "k1_traffic.json")
     try:
         with open(path) as f:
