@@ -136,6 +136,14 @@ static inline int mcx_scratch(mcx_ctx *ctx, size_t bytes, void **out)
 /* word of h_pinned that a read-back kernel stores last (a value that grows with every use) */
 #define MCX_PINNED_SEQ_WORD 40u
 
+/* the next value of the sequence word (never 0: kernels take 0 as "do not report") */
+static inline uint32_t mcx_next_seq(mcx_ctx *ctx)
+{
+    if (++ctx->pinned_seq == 0u)
+        ctx->pinned_seq = 1u;
+    return ctx->pinned_seq;
+}
+
 /* Wait for a read-back kernel on the context's stream: spin on the sequence word it stores
  * last, behind a system-scope fence, into pinned host memory (a few microseconds against
  * about 25 for a stream synchronisation); after 200 us without it, synchronise the stream

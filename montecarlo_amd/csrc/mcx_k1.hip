@@ -1960,10 +1960,14 @@ int mcx_alias_match_list(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uin
     const size_t sbytes = s_off[N];
     const size_t o_off = up256(sbytes ? sbytes : 1), o_loff = o_off + up256(4 * ((size_t)N + 1));
     const size_t o_idx = o_loff + up256(4 * ((size_t)N + 1)), bytes = o_idx + up256(4 * (size_t)(cap ? cap : 1));
+    /* strings, offsets and both result arrays in the context's staging area (kept between calls) */
     char *d = nullptr;
-    if (hipMalloc((void **)&d, bytes) != hipSuccess) {
-        ctx->err = "hipMalloc of the staging buffers failed";
-        return MCX_E_NOMEM;
+    {
+        uint8_t *base = nullptr;
+        const int rc_io = mcx_io_reserve(ctx, bytes, &base);
+        if (rc_io != MCX_OK)
+            return rc_io;
+        d = (char *)base;
     }
     hipError_t e = hipSuccess;
     if (sbytes)
@@ -1990,7 +1994,6 @@ int mcx_alias_match_list(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uin
         }
     }
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
     return rc;
 }
 

@@ -1433,7 +1433,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
      * launches last time in this direction will most likely do so again: its first batch is
      * then enqueued without a look in between. */
     const bool expect_handover = ctx->bfs_depth[direction] != 0u;
-    const uint32_t seq0 = expect_handover ? 0u : ++ctx->pinned_seq;
+    const uint32_t seq0 = expect_handover ? 0u : mcx_next_seq(ctx);
     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[0], queue[1], st, 0u, rep, seq0);
     HIPCHK(ctx, hipGetLastError());
     if (!expect_handover && mcx_wait_seq(ctx, seq0))
@@ -1477,7 +1477,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                                                                       queue[(level + 1u) & 1u], st, level, sweep_waves);
             }
             HIPCHK(ctx, hipGetLastError());
-            k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, rep, ++ctx->pinned_seq);
+            k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, rep, mcx_next_seq(ctx));
             HIPCHK(ctx, hipGetLastError());
             if (mcx_wait_seq(ctx, ctx->pinned_seq))
                 return MCX_E_HIP;
