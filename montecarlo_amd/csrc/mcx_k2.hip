@@ -186,7 +186,9 @@ k2_flags_rows(const uint32_t *__restrict__ rrowptr, const uint32_t *__restrict__
 #endif
 #define K2P_THREADS 1024u
 #define K2P_WAVES (K2P_THREADS / 64u)
+#ifndef K2P_ROWS_PRE
 #define K2P_ROWS_PRE 8u /* rows per thread whose pointers and flag bytes are requested at the start */
+#endif
 #ifndef K2P_ROW_WEIGHT
 #define K2P_ROW_WEIGHT 6u /* a row costs about as much as this many holder entries */
 #endif
