@@ -842,6 +842,9 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
  * share a block.
  */
 #define K1T_THREADS 256u
+#ifndef K1T_MIN_WAVES
+#define K1T_MIN_WAVES 4 /* waves per SIMD the register allocation leaves room for */
+#endif
 #define K1T_WAVES (K1T_THREADS / 64u)
 #define K1T_MAX_SPB 64u
 #define K1T_STR_BYTES 5120u  /* staging buffer of a tile; a tile that needs more is read in place */
@@ -867,7 +870,7 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
 #define K1_EMIT_NARROW 8u /* lists up to this length are written by one thread, longer ones by a wave */
 
 template <int MODE>
-__global__ void __launch_bounds__(K1T_THREADS, 4)
+__global__ void __launch_bounds__(K1T_THREADS, K1T_MIN_WAVES)
 k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
                uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
                uint32_t *__restrict__ count, const k1_list_t L)
