@@ -190,7 +190,11 @@ int mcx_dep_flags_noalloc_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_
  * transitive holders (what must be unloaded before the seeds, the situation
  * the reference reports at desktop/ui.py:1679-1680); MCX_CLOSURE_DEPS: out =
  * everything the seeds transitively need.  Seeds that are LOADED are part of
- * the result.  edges_scanned / levels are optional outputs.
+ * the result.  edges_scanned / levels are optional outputs.  There is no limit
+ * on the depth of a search.  Unlike the other *_dev entry points, the _dev form
+ * does not return before the search is over: its length is only known on the
+ * device, so the call enqueues levels a batch at a time and waits for each
+ * batch's frontier sizes (the out bitmap is complete when it returns).
  */
 int mcx_dep_closure(mcx_ctx *ctx, const uint8_t *in_flags, const uint32_t *seed_bitmap,
                     uint32_t *out_bitmap, int direction,
