@@ -21,7 +21,10 @@
  * Buffers named d_* are device pointers (hipMalloc memory or any pointer the
  * HIP runtime accepts on the context's device); all others are host pointers.
  * A context owns (or borrows) one HIP stream; *_dev entry points only enqueue
- * work on it and return, host-buffer entry points synchronise before returning.
+ * work on it and return, except the ones that hand a total or a count back to
+ * the host (mcx_dep_closure_dev, mcx_alias_match_list_dev, the fleet calls, the
+ * device filter: each says so), which wait for that number; host-buffer entry
+ * points synchronise before returning.
  * A context is not thread safe: use one per thread.
  */
 #ifndef MCX_H
