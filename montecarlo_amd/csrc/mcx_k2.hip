@@ -789,6 +789,12 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
  * With `rep.seq` set it reports to the host when it returns (and clears the
  * state if the search is over).
  */
+#ifndef K2B_TAIL
+#define K2B_TAIL 2u        /* levels a batch is longer than the last search in that direction */
+#endif
+#ifndef K2B_SMALL_EVERY
+#define K2B_SMALL_EVERY 2u /* the one-workgroup kernel goes in front of every so many levels */
+#endif
 #define K2S_THREADS 1024u
 #define K2S_CAP 2048u
 #define K2S_PER 4u
@@ -1451,7 +1457,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
          * the counter window can be restarted at a batch boundary).  The window of
          * K2B_MAX_LEVELS per-level counters is reused as often as needed. */
         const uint32_t hint = ctx->bfs_depth[direction];
-        uint32_t batch = hint ? (hint + 2u < 4u ? 4u : (hint + 2u > K2B_BATCH ? K2B_BATCH : hint + 2u)) : 8u;
+        uint32_t batch = hint ? (hint + K2B_TAIL < 4u ? 4u : (hint + K2B_TAIL > K2B_BATCH ? K2B_BATCH : hint + K2B_TAIL)) : 8u;
         batch = (batch + 1u) & ~1u;
         uint32_t base = 0; /* level of the counter window the next batch starts at */
         bool done = false;
@@ -1471,7 +1477,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
             }
             for (uint32_t b = 0; b < batch; ++b) {
                 const uint32_t level = base + b;
-                if (b != 0u && !(b & 1u))
+                if (b != 0u && b % K2B_SMALL_EVERY == 0u)
                     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[level & 1u],
                                                                   queue[(level + 1u) & 1u], st, level, none, 0u);
                 k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, queue[level & 1u],
