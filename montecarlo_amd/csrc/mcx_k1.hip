@@ -1301,22 +1301,24 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
  * pattern text stands for one table position, or for several (its copies, ascending in
  * dup_idx): the string's list is the merge of these few ascending runs, cut at `want`
  * entries (the size of the string's place in list_idx).  Strings with more matching
- * texts than a short list holds are counted in *overflow and left alone.
+ * texts than a short list holds are left alone (k1_list_cap has counted them).
  */
 __global__ void __launch_bounds__(256)
 k1_list_emit(const uint32_t *__restrict__ nslots, const uint32_t *__restrict__ slots,
              const uint32_t *__restrict__ slot_tab, const uint32_t *__restrict__ dup_start,
              const uint32_t *__restrict__ dup_idx, const uint32_t *__restrict__ off, uint32_t N,
-             uint32_t *__restrict__ idx, uint32_t *__restrict__ overflow)
+             uint32_t *__restrict__ idx, const unsigned long long *__restrict__ totals, unsigned long long cap)
 {
+    /* enqueued before the host has seen the totals: nothing is written when the lists do not
+     * fit the caller's array or some short list overflowed (the caller then takes another way) */
+    if (totals[0] > cap || totals[0] > 0xFFFFFFFFull || totals[1] != 0ull)
+        return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
     const uint32_t ns = nslots[i];
-    if (ns > K1T_LIST_CAP) {
-        atomicAdd(overflow, 1u);
+    if (ns > K1T_LIST_CAP)
         return;
-    }
     const uint32_t want = off[i + 1] - off[i];
     if (want == 0u || want > K1_EMIT_NARROW)
         return; /* nothing to write, or k1_list_emit_wide's */
@@ -1413,8 +1415,10 @@ __global__ void __launch_bounds__(256)
 k1_list_emit_wide(const uint32_t *__restrict__ nslots, const uint32_t *__restrict__ slots,
                   const uint32_t *__restrict__ slot_tab, const uint32_t *__restrict__ dup_start,
                   const uint32_t *__restrict__ dup_idx, const uint32_t *__restrict__ off, uint32_t N,
-                  uint32_t *__restrict__ idx)
+                  uint32_t *__restrict__ idx, const unsigned long long *__restrict__ totals, unsigned long long cap)
 {
+    if (totals[0] > cap || totals[0] > 0xFFFFFFFFull || totals[1] != 0ull)
+        return; /* as in k1_list_emit */
     __shared__ const uint32_t *rptr[4][K1T_LIST_CAP];
     __shared__ uint32_t rlen[4][K1T_LIST_CAP], rhead[4][K1T_LIST_CAP], rbase[4][K1T_LIST_CAP + 1u];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1878,6 +1882,19 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
     unsigned long long *dh_total = nullptr; /* the pinned words as the device addresses them */
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&dh_total, h_total, 0));
     k1_publish2<<<1, 64, 0, ctx->stream>>>(d_total, dh_total);
+    /* the lists themselves are enqueued before the host looks at the totals (the kernels look
+     * for themselves and write nothing when the lists do not fit or a short list overflowed):
+     * the device does not sit idle through the host's round trip */
+    const bool emitted = !ctx->list_two_pass && d_list_idx != nullptr;
+    if (emitted) {
+        k1_list_emit<<<grid, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start, ctx->d_dup_idx,
+                                                    (const uint32_t *)d_list_off, N, (uint32_t *)d_list_idx, d_total,
+                                                    (unsigned long long)cap);
+        k1_list_emit_wide<<<(N + 3u) / 4u, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start,
+                                                                 ctx->d_dup_idx, (const uint32_t *)d_list_off, N,
+                                                                 (uint32_t *)d_list_idx, d_total,
+                                                                 (unsigned long long)cap);
+    }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const unsigned long long kept = h_total[0];
@@ -1893,15 +1910,8 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
     }
     if (kept == 0)
         return MCX_OK;
-    if (overflows == 0u && !ctx->list_two_pass) {
-        k1_list_emit<<<grid, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start, ctx->d_dup_idx,
-                                                    (const uint32_t *)d_list_off, N, (uint32_t *)d_list_idx, d_over);
-        k1_list_emit_wide<<<(N + 3u) / 4u, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start,
-                                                                 ctx->d_dup_idx, (const uint32_t *)d_list_off, N,
-                                                                 (uint32_t *)d_list_idx);
-        HIPCHK(ctx, hipGetLastError());
-        return MCX_OK;
-    }
+    if (overflows == 0u && emitted)
+        return MCX_OK; /* written already */
     /* some string is matched by more pattern texts than a short list holds (or the test seam
      * asks for it): the lists are filled by a second pass of the kernel and sorted */
     uint32_t *full_off = (uint32_t *)d_list_off, *full_idx = (uint32_t *)d_list_idx;
