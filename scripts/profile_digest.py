@@ -51,22 +51,25 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
-    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/profile_round.sh), median per "
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --no-cpu --no-fleet "
+            "--no-configs3 (scripts/profile_round.sh), median per "
             "launch in KiB; FETCH_SIZE doubled for bytes (gfx950 counts 128-byte requests as 64 bytes)")
 
     stats = glob.glob(os.path.join(src, "bench_stats", "**", "*kernel_stats.csv"), recursive=True)
     shutil.copy(stats[0], os.path.join(dst, tag + "_bench_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_line_under_profiler.json"), os.path.join(dst, tag + "_bench_under_profiler.json"))
 
-    k1 = traffic(src, "k1_fetch", "k1_write", "k1_match_small")
+    k1 = traffic(src, "bench_fetch", "bench_write", "k1_match_small")
     k1.update({"strings": 1000, "patterns": 30000, "kernel": "k1_match_small", "note": note})
     with open(os.path.join(dst, "k1_traffic.json"), "w") as f:
         json.dump(k1, f, indent=1)
 
-    k2 = {"workload": "configs[2]: V=1000000 modules, E=10007521 edges (scripts/k2time.py)", "note": note}
+    k2 = {"workload": "configs[2]: V=1000000 modules, E=10007521 edges (the k2 block of bench.py)", "note": note}
     total = 0
-    for kern in kernels_in(os.path.join(src, "k2_fetch"), "k2_") + kernels_in(os.path.join(src, "k2_fetch"), "void k2_"):
-        k2[kern] = traffic(src, "k2_fetch", "k2_write", kern)
+    for kern in kernels_in(os.path.join(src, "bench_fetch"), "k2_") + kernels_in(os.path.join(src, "bench_fetch"), "void k2_"):
+        if kern.startswith("k2b_"):
+            continue  # the closure's kernels: their traffic depends on the seeds, not a per-call figure
+        k2[kern] = traffic(src, "bench_fetch", "bench_write", kern)
         total += k2[kern]["hbm_bytes_per_launch"]
     k2["algorithmic_bytes_per_call"] = 4 * (1000000 + 1) + 4 * 10007521 + 2 * 1000000
     k2["hbm_bytes_per_call"] = total

@@ -21,10 +21,11 @@ step() { # name, seconds, command...
 step bench_stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- \
     python3 bench.py --steps 200 --warmup 20
 tail -n 1 "$OUT/bench_stats.log" > "$OUT/bench_line_under_profiler.json"
-step k1_fetch 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/k1_fetch" -- python3 scripts/k1time.py
-step k1_write 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/k1_write" -- python3 scripts/k1time.py
-step k2_fetch 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/k2_fetch" -- python3 scripts/k2time.py
-step k2_write 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/k2_write" -- python3 scripts/k2time.py
+# HBM traffic of the bench's own kernels: the same command without its CPU legs and large cases
+step bench_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_fetch" -- \
+    python3 bench.py --no-cpu --no-fleet --no-configs3 --repeats 3
+step bench_write 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_write" -- \
+    python3 bench.py --no-cpu --no-fleet --no-configs3 --repeats 3
 export K1_N=1000000 K1_REPS=5
 step k1_tiles_sq1 180 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES \
     SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/k1_tiles_sq1" -- \
