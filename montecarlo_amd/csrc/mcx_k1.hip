@@ -1219,6 +1219,8 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
     /* ---- probe: a lane per (string, key length) ------------------------------ */
     __syncthreads();
     const uint32_t nprobe = K1T_SKIP <= 1 ? 0u : nstr * T.nlens;
+    /* ceil(2^32 / nstr): x / nstr = mulhi(x, magic) for x < 2^16, nstr >= 2 */
+    const uint32_t nstr_magic = nstr > 1u ? (uint32_t)((0x100000000ull + nstr - 1u) / nstr) : 0u;
     uint32_t rbound = 0, bbound = 0; /* no more runs / pairs than these are queued */
     for (uint32_t p0 = 0; p0 < nprobe; p0 += K1T_THREADS) {
         /* a step adds at most one run or one pair per lane */
@@ -1241,7 +1243,12 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
         bbound += K1T_THREADS;
         const uint32_t pr = p0 + tid;
         if (pr < nprobe) {
-            const uint32_t slot = T.nlens == 1u ? pr : __umulhi(pr, T.nlens_magic), KL = key_lens[pr - slot * T.nlens];
+            /* key length by key length over all strings of the tile, not string by string: the
+             * lanes of a step then hash keys of one length, and what the later phases are handed
+             * comes sorted by key length - the patterns of one group, of similar shape, side by
+             * side in the survivor queue instead of every string's mix of short and long programs */
+            const uint32_t li = nstr == 1u ? pr : __umulhi(pr, nstr_magic), slot = pr - li * nstr;
+            const uint32_t KL = key_lens[li];
             const uint32_t len = str_len[slot];
             if (KL <= len) {
                 uint32_t kw[MCX_KEY_MAX / 4];
