@@ -853,7 +853,9 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
 #define K1T_SCAP 1024u       /* survivors waiting for a program run                  */
 #define K1T_SUB_MAX_LEN 67u  /* strings up to this length go through the second index: one
                                 lane per 4-byte window; longer ones have the whole group screened */
+#ifndef K1T_PAIRS
 #define K1T_PAIRS 4u         /* pairs a wave looks up at a time */
+#endif
 #define K1T_SUB_SPARE (2u * K1T_WAVES * K1T_PAIRS) /* runs a turn adds whatever happens: one for the
                                 patterns without an anchor gram and one fallback per pair */
 
