@@ -842,15 +842,33 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
  * share a block.
  */
 #define K1T_THREADS 256u
+/* Six blocks per CU: the kernel is a chain of short dependent steps, and every resident block
+ * more hides more of them (10^6 strings x 30 000 patterns: 1.14 ms with four blocks, 0.96 with
+ * five, 0.84 with six, the same with seven).  Six means at most 84 registers (80 used, three
+ * spilled) and at most 26 880 bytes of LDS per block, which is what the queue sizes below are
+ * cut to: LDS is handed out in pieces of 1280 bytes. */
 #ifndef K1T_MIN_WAVES
-#define K1T_MIN_WAVES 4 /* waves per SIMD the register allocation leaves room for */
+#define K1T_MIN_WAVES 6 /* waves per SIMD the register allocation leaves room for */
 #endif
 #define K1T_WAVES (K1T_THREADS / 64u)
+#ifndef K1T_RESIDENT
+#define K1T_RESIDENT (K1T_MIN_WAVES * 256u) /* blocks of this kernel the 256 CUs hold at once */
+#endif
 #define K1T_MAX_SPB 64u
+#ifndef K1T_STR_BYTES
 #define K1T_STR_BYTES 5120u  /* staging buffer of a tile; a tile that needs more is read in place */
-#define K1T_RCAP 1024u       /* candidate runs waiting for the screen (four per thread) */
-#define K1T_BCAP 384u        /* (string, large group) pairs waiting for the second index */
+#endif
+#ifndef K1T_RPT
+#define K1T_RPT 3u           /* candidate runs per thread the screen's queue holds */
+#endif
+#define K1T_RCAP (K1T_RPT * K1T_THREADS) /* candidate runs waiting for the screen */
+#ifndef K1T_BCAP
+#define K1T_BCAP 288u        /* (string, large group) pairs waiting for the second index; a probe
+                                step adds up to K1T_THREADS of them */
+#endif
+#ifndef K1T_SCAP
 #define K1T_SCAP 1024u       /* survivors waiting for a program run                  */
+#endif
 #define K1T_SUB_MAX_LEN 67u  /* strings up to this length go through the second index: one
                                 lane per 4-byte window; longer ones have the whole group screened */
 #ifndef K1T_PAIRS
@@ -1031,12 +1049,12 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
     auto drain_runs = [&]() __attribute__((always_inline)) {
         /* called by all threads behind a barrier */
         const uint32_t nr = K1T_SKIP <= 3 ? 0u : nruns_sh;
-        /* exclusive sums of the run sizes, four runs per thread */
+        /* exclusive sums of the run sizes, K1T_RPT runs per thread */
         {
-            uint32_t c[4], mine = 0;
+            uint32_t c[K1T_RPT], mine = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                const uint32_t r = 4u * tid + k;
+            for (uint32_t k = 0; k < K1T_RPT; ++k) {
+                const uint32_t r = K1T_RPT * tid + k;
                 c[k] = r < nr ? (run_cnt[r] & 0x03FFFFFFu) : 0u;
                 mine += c[k];
             }
@@ -1056,12 +1074,12 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                 if (k < wave)
                     at += wsum[k];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                run_cum[4u * tid + k] = at;
+            for (uint32_t k = 0; k < K1T_RPT; ++k) {
+                run_cum[K1T_RPT * tid + k] = at;
                 at += c[k];
             }
             if (tid == K1T_THREADS - 1u)
-                run_cum[K1T_RCAP] = at; /* K1T_RCAP = 4 x K1T_THREADS: the sum over all entries */
+                run_cum[K1T_RCAP] = at; /* K1T_RCAP = K1T_RPT x K1T_THREADS: the sum over all entries */
             __syncthreads();
         }
         const uint32_t ncand = run_cum[nr];
@@ -1671,10 +1689,10 @@ static void k1_fill_table(const mcx_ctx *ctx, k1_table_t &T)
 }
 
 /* Which of the two kernels a batch gets.  The small-batch kernel (a handful of strings per
- * block, occurrence tables, eight lanes per program run) is faster while the batch does not
- * fill the chip several times over; the tile kernel (up to 64 strings per block) from about
- * 24 000 strings on (measured against 3 x 10^4 patterns: 46 / 56 us at 16 384 strings, 92 /
- * 70 us at 32 768).  Only the tile kernel uses the second index of the large groups, and
+ * block, occurrence tables, eight lanes per program run) is faster for a few thousand strings;
+ * the tile kernel (up to 64 strings per block) from about 7000 strings on (measured against
+ * 3 x 10^4 patterns, small / tile: 23 / 28 us at 4096 strings, 29 / 30 at 6144, 33 / 32 at 8192,
+ * 42 / 34 at 12 288, 71 / 42 at 24 576).  Only the tile kernel uses the second index of the large groups, and
  * against a table with a very large group (every "of:" line of a table of 3 x 10^6 patterns
  * shares one prefix) that decides it whatever the batch: 1000 strings take 28 us with it
  * and 78 us without.  Test seam: MCX_BULK_MIN in the environment, read once when the table
@@ -1683,12 +1701,29 @@ static bool k1_use_tiles(const mcx_ctx *ctx, uint32_t N)
 {
     if (ctx->bulk_min_set)
         return N >= ctx->bulk_min;
-    if (N >= 24576u)
+    if (N >= 7168u)
         return true;
-    /* the larger the largest group, the earlier the second index pays: 7000 strings against
-     * 10^5 patterns (largest group 3900), any batch from 8192 patterns in one group on */
+    /* the larger the largest group, the earlier the second index pays: any batch from 8192
+     * patterns in one group on */
     return ctx->n_sub_groups != 0u &&
            (ctx->max_group >= 8192u || (uint64_t)N * ctx->max_group >= 24000000ull);
+}
+
+/* Strings per block of the tile kernel: the chip holds K1T_RESIDENT blocks at once, and a launch
+ * of a few more than that ends with a nearly empty second round (100 000 strings: 139 us as 1563
+ * blocks of 64 strings, 126 as 2041 of 49).  So: the number of rounds the batch needs with full
+ * tiles, and then the tile size that fills those rounds evenly. */
+static uint32_t k1t_strings_per_block(uint32_t N)
+{
+    const uint64_t full = (uint64_t)K1T_MAX_SPB * K1T_RESIDENT;
+    const uint64_t rounds = (N + full - 1u) / full;
+    if (rounds >= 4u)
+        return K1T_MAX_SPB; /* many rounds: the last one's emptiness no longer shows, full tiles do */
+    const uint64_t blocks = rounds * K1T_RESIDENT;
+    uint32_t spb = (uint32_t)((N + blocks - 1u) / blocks);
+    if (spb > K1T_MAX_SPB)
+        spb = K1T_MAX_SPB;
+    return spb ? spb : 1u;
 }
 
 static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
@@ -1703,8 +1738,7 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     uint32_t spb = (N + 2047u) / 2048u;
 #ifndef MCX_K1_STAMPS
     if (k1_use_tiles(ctx, N)) {
-        if (spb > K1T_MAX_SPB)
-            spb = K1T_MAX_SPB;
+        spb = k1t_strings_per_block(N);
         k1_match_tiles<0><<<(N + spb - 1u) / spb, K1T_THREADS, 0, ctx->stream>>>(d_S, d_s_off, N, spb, s_aligned, T,
                                                                                   d_first, d_count, k1_list_t{});
         HIPCHK(ctx, hipGetLastError());
@@ -1834,9 +1868,7 @@ static int launch_tiles_list(mcx_ctx *ctx, int mode, const uint8_t *d_S, const u
 {
     k1_table_t T;
     k1_fill_table(ctx, T);
-    uint32_t spb = (N + 2047u) / 2048u;
-    if (spb > K1T_MAX_SPB)
-        spb = K1T_MAX_SPB;
+    const uint32_t spb = k1t_strings_per_block(N);
     const uint32_t blocks = (N + spb - 1u) / spb;
     const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
     if (mode == 1)
