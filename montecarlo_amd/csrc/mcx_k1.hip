@@ -16,6 +16,9 @@
 /* ------------------------------------------------------------------------- */
 
 #define K1_THREADS 256
+#ifndef K1_MIN_WAVES
+#define K1_MIN_WAVES 4 /* waves per SIMD the small-batch kernel's register allocation leaves room for */
+#endif
 #define K1_WAVES (K1_THREADS / 64)
 #define K1_MAX_SPB 8                        /* strings per block, at most      */
 #define K1_OCC_WORDS 512                     /* 256 x 64-bit position sets      */
@@ -241,7 +244,7 @@ __device__ __attribute__((noinline)) void k1_normalize_tile(uint32_t *str_w, con
     }
 }
 
-__global__ void __launch_bounds__(K1_THREADS, 4)
+__global__ void __launch_bounds__(K1_THREADS, K1_MIN_WAVES)
 k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
                uint32_t str_cap, uint32_t s_aligned, const k1_table_t T,
                uint32_t *__restrict__ first_idx, uint32_t *__restrict__ count
