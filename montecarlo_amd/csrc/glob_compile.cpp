@@ -687,15 +687,19 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         }
         out.slots[at] = sl;
     }
-    out.tags.resize(cap);
-    for (size_t at = 0; at < cap; ++at)
-        out.tags[at] = out.slots[at].count ? (uint8_t)mcx_key_tag(out.slots[at].hash) : 0u;
+    /* the tag arrays repeat their first three bytes behind the last one: a reader takes the
+     * tags of four consecutive entries as one word from any entry on */
+    out.tags.resize(cap + 3);
+    for (size_t at = 0; at < cap + 3; ++at) {
+        const mcx_slot_t &sl = out.slots[at & (cap - 1)];
+        out.tags[at] = sl.count ? (uint8_t)mcx_key_tag(sl.hash) : 0u;
+    }
     /* second index, never empty, one entry in four used */
     size_t scap = 16;
     while (scap < 4 * sub_runs.size())
         scap *= 2;
     out.sub.assign(scap, mcx_sub_t{0, 0, 0, 0});
-    out.sub_tags.assign(scap, 0u);
+    out.sub_tags.assign(scap + 3, 0u);
     for (const SubRun &r : sub_runs) {
         const uint32_t h = mcx_sub_hash(r.gram, r.gid);
         size_t at = h & (scap - 1);
@@ -704,5 +708,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         out.sub[at] = mcx_sub_t{r.gram, r.gid, r.start, r.count};
         out.sub_tags[at] = (uint8_t)mcx_key_tag(h);
     }
+    for (size_t at = 0; at < 3; ++at)
+        out.sub_tags[scap + at] = out.sub_tags[at];
     return 0;
 }

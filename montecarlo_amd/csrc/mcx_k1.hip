@@ -885,6 +885,32 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
 #define K1T_SKIP 99
 #endif
 
+/* The tag bytes of four consecutive index entries from entry `at` on, lowest byte first.  The
+ * tag arrays carry their first three bytes once more behind the last one, so a word read at any
+ * entry stays inside and sees the walk wrap around. */
+__device__ __forceinline__ uint32_t k1_tags4(const uint8_t *tags, uint32_t at)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, tags + at, 4);
+    return v;
+}
+
+/* 0x80 in every byte of x that is zero; bytes above the lowest zero byte may be flagged wrongly */
+__device__ __forceinline__ uint32_t k1_zero_bytes(uint32_t x)
+{
+    return (x - 0x01010101u) & ~x & 0x80808080u;
+}
+
+/* all bits below the lowest set bit of m (everything for m = 0) */
+__device__ __forceinline__ uint32_t k1_below_lowest(uint32_t m)
+{
+    return (m & (0u - m)) - 1u;
+}
+
+#define K1T_DEDUP_BITS 7u
+#define K1T_DEDUP_CELLS (1u << K1T_DEDUP_BITS)
+static_assert(K1T_DEDUP_CELLS * K1T_WAVES <= K1T_RCAP, "the second index borrows the run sums' room");
+
 /* MODE 0: first_idx and count.  MODE 1: the same plus, per string, the slots of the pattern
  * texts that matched (up to K1T_LIST_CAP, written to global memory as they are found): the match lists of
  * nearly every string follow from those without a second pass.  MODE 2: every match is written
@@ -1164,7 +1190,7 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                         act[i] = true;
                         w[i] = word_of(slot, lane);
                         h[i] = mcx_sub_hash(w[i], key[i] >> 6);
-                        tag[i] = T.sub_tags[h[i] & T.sub_mask];
+                        tag[i] = k1_tags4(T.sub_tags, h[i] & T.sub_mask);
                     }
                 }
             }
@@ -1176,30 +1202,48 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                 bool found = false;
                 uint32_t fstart = 0, fcnt = 0;
                 if (act[i]) {
-                    const uint32_t tg = mcx_key_tag(h[i]), gid = key[i] >> 6;
-                    uint32_t t = tag[i];
-                    for (uint32_t p = h[i] & T.sub_mask; t != 0u; p = (p + 1u) & T.sub_mask, t = T.sub_tags[p]) {
-                        if (t != tg)
-                            continue;
-                        const mcx_sub_t en = T.sub[p];
-                        if (en.gram == w[i] && en.gid == gid) {
-                            found = true;
-                            fstart = en.start;
-                            fcnt = en.count;
-                            break;
+                    const uint32_t tg = mcx_key_tag(h[i]) * 0x01010101u, gid = key[i] >> 6;
+                    uint32_t t4 = tag[i];
+                    for (uint32_t p = h[i] & T.sub_mask;; p = (p + 4u) & T.sub_mask, t4 = k1_tags4(T.sub_tags, p)) {
+                        const uint32_t empty = k1_zero_bytes(t4);
+                        uint32_t cand = k1_zero_bytes(t4 ^ tg) & k1_below_lowest(empty);
+                        while (cand != 0u && !found) {
+                            const mcx_sub_t en = T.sub[(p + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.sub_mask];
+                            cand &= cand - 1u;
+                            if (en.gram == w[i] && en.gid == gid) {
+                                found = true;
+                                fstart = en.start;
+                                fcnt = en.count;
+                            }
                         }
+                        if (found || empty != 0u)
+                            break;
                     }
                 }
-                /* a gram that occurs twice in the string names its run once: the lowest lane
-                 * holding these four bytes keeps it */
-                unsigned long long todo = __ballot(found);
-                while (todo) {
-                    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(todo));
-                    const uint32_t wl = __builtin_amdgcn_readlane(w[i], l);
-                    const unsigned long long same = __ballot(act[i] && w[i] == wl);
-                    if (lane == l && (uint32_t)__builtin_ctzll(same) != l)
+                /* a gram that occurs twice in the string names its run once.  The lanes that
+                 * found something write their number into a cell of a small table chosen by
+                 * the gram (the sums of the run sizes are not in use during a turn: their room
+                 * serves), and whoever reads his own number back keeps the run.  Two different
+                 * grams in one cell: the long way round, lane by lane. */
+                if (const unsigned long long fm0 = __ballot(found); (fm0 & (fm0 - 1ull)) != 0ull) {
+                    volatile uint32_t *cell = run_cum + K1T_DEDUP_CELLS * wave + ((w[i] * 0x9E3779B1u) >> (32u - K1T_DEDUP_BITS));
+                    if (found)
+                        *cell = lane;
+                    const uint32_t winner = found ? *cell : lane;
+                    const uint32_t theirs = __shfl(w[i], (int)winner, 64);
+                    if (__ballot(found && theirs != w[i]) != 0ull) {
+                        unsigned long long todo = fm0;
+                        while (todo) {
+                            const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(todo));
+                            const uint32_t wl = __builtin_amdgcn_readlane(w[i], l);
+                            const unsigned long long same = __ballot(found && w[i] == wl);
+                            if (found && w[i] == wl && lane != l)
+                                found = false;
+                            todo &= ~same;
+                        }
+                    } else if (winner != lane) {
                         found = false;
-                    todo &= ~(1ull << l);
+                    }
                 }
                 const unsigned long long fm = __ballot(found);
                 const uint32_t nf = (uint32_t)__popcll(fm), slot = key[i] & 63u;
@@ -1282,29 +1326,34 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                 for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
                     if ((KL >> 2) == k && (KL & 3u))
                         kw[k] &= 0xFFFFFFFFu >> (8u * (4u - (KL & 3u)));
-                const uint32_t a = mcx_key_hash(kw, KL), my_tag = mcx_key_tag(a);
-                for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
-                    const uint32_t tag = T.tags[at];
-                    if (tag == 0u)
-                        break;
-                    if (tag != my_tag)
-                        continue;
-                    const mcx_slot_t sl = T.slots[at];
-                    bool same = sl.hash == a && sl.len == KL;
+                const uint32_t a = mcx_key_hash(kw, KL), my_tag = mcx_key_tag(a) * 0x01010101u;
+                /* four tag bytes a step: nearly every walk ends inside the first word */
+                bool done = false;
+                for (uint32_t at = a & T.slot_mask; !done; at = (at + 4u) & T.slot_mask) {
+                    const uint32_t t4 = k1_tags4(T.tags, at);
+                    const uint32_t empty = k1_zero_bytes(t4);
+                    uint32_t cand = k1_zero_bytes(t4 ^ my_tag) & k1_below_lowest(empty);
+                    done = empty != 0u;
+                    while (cand != 0u) {
+                        const mcx_slot_t sl = T.slots[(at + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.slot_mask];
+                        cand &= cand - 1u;
+                        bool same = sl.hash == a && sl.len == KL;
 #pragma unroll
-                    for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
-                        same = same && sl.key[k] == kw[k];
-                    if (same) {
-                        if (sl.pad[0] != 0u && use_lds && len <= K1T_SUB_MAX_LEN) {
-                            const uint32_t bi = atomicAdd(&nbig_sh, 1u);
-                            big_key[bi] = slot | ((sl.pad[0] - 1u) << 6);
-                            big_start[bi] = sl.start;
-                            big_count[bi] = sl.count;
-                            big_rest[bi] = sl.pad[1];
-                        } else {
-                            push_run(sl.start, sl.count, slot);
+                        for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
+                            same = same && sl.key[k] == kw[k];
+                        if (same) {
+                            if (sl.pad[0] != 0u && use_lds && len <= K1T_SUB_MAX_LEN) {
+                                const uint32_t bi = atomicAdd(&nbig_sh, 1u);
+                                big_key[bi] = slot | ((sl.pad[0] - 1u) << 6);
+                                big_start[bi] = sl.start;
+                                big_count[bi] = sl.count;
+                                big_rest[bi] = sl.pad[1];
+                            } else {
+                                push_run(sl.start, sl.count, slot);
+                            }
+                            done = true;
+                            break;
                         }
-                        break;
                     }
                 }
             }
