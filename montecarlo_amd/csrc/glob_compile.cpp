@@ -480,6 +480,89 @@ static uint32_t sig_of(const mcx_pattern_ir &ir, size_t keylen)
 
 /* the distinct four-literal windows of the pattern that are not wholly inside
  * the index key: every string the pattern matches holds each of them */
+/* signature from up to four grams picked by the caller */
+static uint32_t sig_from(const std::vector<uint32_t> &grams)
+{
+    uint32_t bits[4], nb = 0;
+    for (uint32_t g : grams) {
+        const uint32_t b = mcx_gram_bit(g);
+        bool have = false;
+        for (uint32_t k = 0; k < nb; ++k)
+            have = have || bits[k] == b;
+        if (!have && nb < 4)
+            bits[nb++] = b;
+    }
+    uint32_t sig = 0;
+    for (uint32_t k = 0; k < 4; ++k)
+        sig |= (k < nb ? bits[k] : (nb ? bits[0] : MCX_BLOOM_FREE)) << (8u * k);
+    return sig;
+}
+
+/*
+ * The patterns that are screened side by side - a group, or inside a large group the run of
+ * one anchor gram - mostly differ in a few bytes ("bc0Csc03i30" / "bc0Csc03i00"), and a string
+ * that reaches them holds what they share.  Only the grams that tell them apart reject
+ * anything, so each pattern's signature takes the grams fewest of its neighbours hold
+ * (ties: the rarer one in the whole group, then the later one in the pattern), spread over
+ * the pattern.
+ * cand[i]: the grams of neighbour i; sig_choice[ids[i]] gets the signature.
+ */
+static void choose_sigs(const std::vector<std::vector<uint32_t>> &cand, const uint32_t *ids, size_t first, size_t n,
+                        const std::unordered_map<uint32_t, uint32_t> *group_freq, std::vector<uint32_t> &sig_choice,
+                        std::vector<uint8_t> &sig_chosen)
+{
+    if (n < 2)
+        return;
+    std::unordered_map<uint32_t, uint32_t> here;
+    for (size_t i = first; i < first + n; ++i)
+        for (uint32_t g : cand[i])
+            here[g]++;
+    struct Pick {
+        uint32_t near, wide, at, gram;
+    };
+    std::vector<Pick> picks;
+    std::vector<uint32_t> chosen;
+    for (size_t i = first; i < first + n; ++i) {
+        if (cand[i].size() <= 4)
+            continue; /* all of them fit the signature anyway */
+        picks.clear();
+        for (size_t a = 0; a < cand[i].size(); ++a) {
+            const uint32_t g = cand[i][a];
+            uint32_t wide = 0;
+            if (group_freq) {
+                auto it = group_freq->find(g);
+                wide = it == group_freq->end() ? 0u : it->second;
+            }
+            picks.push_back(Pick{here[g], wide, (uint32_t)a, g});
+        }
+        std::sort(picks.begin(), picks.end(), [](const Pick &x, const Pick &y) {
+            if (x.near != y.near)
+                return x.near < y.near;
+            if (x.wide != y.wide)
+                return x.wide < y.wide;
+            return x.at > y.at;
+        });
+        /* rarest first, but spread over the pattern: grams three or more places apart share at
+         * most one byte, so four of them watch (nearly) sixteen bytes instead of seven */
+        chosen.clear();
+        uint32_t taken[4];
+        for (int pass = 0; pass < 2 && chosen.size() < 4; ++pass)
+            for (size_t a = 0; a < picks.size() && chosen.size() < 4; ++a) {
+                bool ok = true;
+                for (size_t t = 0; t < chosen.size(); ++t) {
+                    const uint32_t gap = picks[a].at > taken[t] ? picks[a].at - taken[t] : taken[t] - picks[a].at;
+                    ok = ok && (pass == 0 ? gap >= 3u : gap != 0u);
+                }
+                if (ok) {
+                    taken[chosen.size()] = picks[a].at;
+                    chosen.push_back(picks[a].gram);
+                }
+            }
+        sig_choice[ids[i]] = sig_from(chosen);
+        sig_chosen[ids[i]] = 1;
+    }
+}
+
 static std::vector<uint32_t> grams_of(const mcx_pattern_ir &ir, size_t keylen)
 {
     std::vector<uint32_t> out;
@@ -574,6 +657,8 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
     const size_t sub_min = sub_env && *sub_env ? (size_t)strtoul(sub_env, nullptr, 10) : (size_t)MCX_SUB_MIN;
     std::vector<SubRun> sub_runs;
     std::unordered_map<uint32_t, SubGroup> sub_groups; /* by group start */
+    std::vector<uint32_t> sig_choice(P, 0u); /* by pattern: the signature picked among its neighbours */
+    std::vector<uint8_t> sig_chosen(P, 0u);
     for (size_t g0 = 0; g0 < n_idx;) {
         size_t g1 = g0 + 1;
         while (g1 < n_idx && keys[order[g1]] == keys[order[g0]])
@@ -590,11 +675,11 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
                     freq[g]++;
             }
             struct Item {
-                uint32_t j, has, gram;
+                uint32_t j, has, gram, ci;
             };
             std::vector<Item> items(g1 - g0);
             for (size_t k = g0; k < g1; ++k) {
-                Item it{order[k], 0u, 0u};
+                Item it{order[k], 0u, 0u, (uint32_t)(k - g0)};
                 uint32_t best = 0xFFFFFFFFu;
                 for (uint32_t g : cand[k - g0]) {
                     const uint32_t f = freq[g];
@@ -627,6 +712,23 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
                 sub_runs.back().count++;
             }
             sub_groups[(uint32_t)g0] = SubGroup{gid, rest};
+            /* signatures: what tells a pattern from the others of its run */
+            std::vector<std::vector<uint32_t>> by_place(g1 - g0);
+            for (size_t k = g0; k < g1; ++k)
+                by_place[k - g0] = std::move(cand[items[k - g0].ci]);
+            for (size_t a = rest; a < g1 - g0;) {
+                size_t b = a + 1;
+                while (b < g1 - g0 && items[b].gram == items[a].gram)
+                    ++b;
+                choose_sigs(by_place, &order[g0], a, b - a, &freq, sig_choice, sig_chosen);
+                a = b;
+            }
+        } else if (g1 - g0 > 1) {
+            const size_t keylen = keys[order[g0]].size();
+            std::vector<std::vector<uint32_t>> cand(g1 - g0);
+            for (size_t k = g0; k < g1; ++k)
+                cand[k - g0] = grams_of(irs[order[k]], keylen);
+            choose_sigs(cand, &order[g0], 0, g1 - g0, nullptr, sig_choice, sig_chosen);
         }
         g0 = g1;
     }
@@ -647,7 +749,7 @@ int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
         groups.back().count++;
         mcx_fill_slot(irs[j], (uint32_t)keys[j].size(), j, mult[j], out.sets,
                       &out.slot[k * (size_t)MCX_SLOT_WORDS], out.ext);
-        out.sig[k] = sig_of(irs[j], keys[j].size());
+        out.sig[k] = sig_chosen[j] ? sig_choice[j] : sig_of(irs[j], keys[j].size());
         if (mult[j] > 1u) {
             out.dup_start[k] = (uint32_t)out.dup_idx.size();
             out.dup_idx.push_back(j);

@@ -1056,17 +1056,25 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
             const uint32_t e = surv[i], slot = e >> 26, kk = e & 0x03FFFFFFu;
             const uint32_t len = str_len[slot];
             const uint32_t *sp = T.slot + (size_t)kk * MCX_SLOT_WORDS;
-            const uint32_t hdr = sp[0];
+            /* header, table position, multiplicity and the first directory word in one request:
+             * a match then has what it reports without another round trip */
+            const uint4 head = *(const uint4 *)sp;
+            static_assert(MCX_SLOT_MULT == 2u && MCX_SLOT_DIR == 3u, "slot words 0..3 as read here");
+            const uint32_t hdr = head.x;
             const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
             const FlatProg fp{is_ext ? T.ext : sp};
-            const uint32_t at = is_ext ? sp[MCX_SLOT_DIR] : MCX_SLOT_BODY;
+            const uint32_t at = is_ext ? head.w : MCX_SLOT_BODY;
             bool ok;
+#if defined(K1T_EXP) && K1T_EXP == 1
+            ok = (hdr & 1u) != 0u || len != 0u;
+#else
             if (use_lds)
                 ok = mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets);
             else
                 ok = mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len, T.norm_dash}, len, T.sets);
+#endif
             if (ok)
-                hit(slot, kk, sp[1], sp[MCX_SLOT_MULT]);
+                hit(slot, kk, head.y, head.z);
         }
         __syncthreads();
         if (tid == 0)

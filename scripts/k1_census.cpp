@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -14,11 +15,12 @@
 #include "../include/mcx.h"
 #include "../montecarlo_amd/csrc/glob_compile.h"
 
+static uint64_t g_words = 0; /* string words read: a measure of a program run's length */
 struct HostStr {
     const uint8_t *p;
     uint32_t len;
     uint32_t byte(uint32_t q) const { return q < len ? p[q] : 0u; }
-    uint32_t word(uint32_t q) const { return byte(q) | (byte(q + 1) << 8) | (byte(q + 2) << 16) | (byte(q + 3) << 24); }
+    uint32_t word(uint32_t q) const { ++g_words; return byte(q) | (byte(q + 1) << 8) | (byte(q + 2) << 16) | (byte(q + 3) << 24); }
 };
 struct HostProg {
     const uint32_t *p;
@@ -50,9 +52,24 @@ int main(int argc, char **argv)
     printf("P=%u distinct=%u groups(lens)=%zu sub_groups=%u max_group=%u\n", P, t.n_distinct, t.lens.size(), t.n_sub_groups, t.max_group);
     const size_t mask = t.slots.size() - 1, smask = t.sub.size() - 1;
     uint64_t hits = 0, cand = 0, surv = 0, match = 0, sub_lookups = 0, sub_found = 0, surv_nogram = 0, bigcand = 0;
-    std::map<uint32_t, uint64_t> surv_by_nseg, cand_by_gsize;
+    std::map<uint32_t, uint64_t> surv_by_nseg, cand_by_gsize, runs_by_size, cand_by_runsize;
     std::map<std::string, uint64_t> fp_shape;
+    std::map<uint64_t, uint64_t> cost_hist;
+    std::vector<uint32_t> tile_cost; /* run lengths of the survivors of the current tile of 64 strings, in order */
+    uint64_t wave_sum = 0, wave_max64 = 0;
     for (uint32_t i = 0; i < N; ++i) {
+        if (i % 64 == 0 || i == N - 1) {
+            /* a lane per survivor, 64 to a wave: a wave takes as long as its longest run */
+            for (size_t a = 0; a < tile_cost.size(); a += 64) {
+                uint32_t mx = 0;
+                for (size_t b = a; b < std::min(a + 64, tile_cost.size()); ++b) {
+                    wave_sum += tile_cost[b];
+                    mx = std::max(mx, tile_cost[b]);
+                }
+                wave_max64 += 64ull * mx;
+            }
+            tile_cost.clear();
+        }
         const uint32_t len = s_off[i + 1] - s_off[i];
         HostStr s{S.data() + s_off[i], len};
         uint32_t bloom[8] = {0};
@@ -85,6 +102,10 @@ int main(int argc, char **argv)
                 } else runs.push_back({sl.start, sl.count});
                 for (auto r : runs) {
                     cand += r.second;
+                    uint32_t bucket = 1;
+                    while (bucket < r.second) bucket *= 2;
+                    runs_by_size[bucket]++;
+                    cand_by_runsize[bucket] += r.second;
                     cand_by_gsize[sl.count <= 4 ? 4 : sl.count <= 64 ? 64 : sl.count <= 1024 ? 1024 : 100000] += r.second;
                     for (uint32_t k = r.first; k < r.first + r.second; ++k) {
                         if (!mcx_sig_pass(t.sig[k], bloom)) continue;
@@ -92,12 +113,17 @@ int main(int argc, char **argv)
                         const uint32_t *slot = &t.slot[(size_t)k * MCX_SLOT_WORDS];
                         if (t.sig[k] == 0xFFFFFFFFu) ++surv_nogram;
                         surv_by_nseg[MCX_HDR_NSEG(slot[0])]++;
+                        const uint64_t words0 = g_words;
                         bool ok = (MCX_HDR_FLAGS(slot[0]) & MCX_PF_EXT)
                                       ? mcx_prog_match(HostProg{t.ext.data()}, slot[MCX_SLOT_DIR], slot[0], s, len, t.sets.data())
                                       : mcx_prog_match(HostProg{slot}, MCX_SLOT_BODY, slot[0], s, len, t.sets.data());
+                        tile_cost.push_back((uint32_t)(g_words - words0));
+                        cost_hist[std::min<uint64_t>(g_words - words0, 63)]++;
                         if (ok) ++match;
                         else if (fp_shape.size() < 100000) {
                             std::string p((const char *)A.data() + a_off[slot[1]], a_off[slot[1] + 1] - a_off[slot[1]]);
+                            if (getenv("CENSUS_EXAMPLES") && i < 40)
+                                printf("  miss: %s  vs  %.*s\n", p.c_str(), (int)len, (const char *)S.data() + s_off[i]);
                             /* shape: digits/hex replaced */
                             for (auto &c : p) if ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'F')) c = 'X';
                             fp_shape[p]++;
@@ -112,6 +138,12 @@ int main(int argc, char **argv)
            (double)hits / N, (double)cand / N, (double)surv / N, (double)surv_nogram / N, (double)match / N,
            (double)sub_lookups / N, (double)sub_found / N);
     for (auto &kv : cand_by_gsize) printf("  candidates from groups <= %u: %.2f per string\n", kv.first, (double)kv.second / N);
+    printf("program runs: %.1f string words read per survivor; lanes busy if a wave waits for its longest run: %.1f of 64\n",
+           (double)wave_sum / surv, 64.0 * wave_sum / wave_max64);
+    for (auto &kv : cost_hist) printf("  runs reading %llu words: %.3f per string\n", (unsigned long long)kv.first, (double)kv.second / N);
+    for (auto &kv : runs_by_size)
+        printf("  runs of up to %u candidates: %.2f per string, %.2f candidates\n", kv.first, (double)kv.second / N,
+               (double)cand_by_runsize[kv.first] / N);
     for (auto &kv : surv_by_nseg) printf("  survivors with %u segments: %.2f per string\n", kv.first, (double)kv.second / N);
     std::vector<std::pair<uint64_t, std::string>> v;
     for (auto &kv : fp_shape) v.push_back({kv.second, kv.first});

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from montecarlo_amd import synth
 seed, P, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 A, a_off, _ = synth.alias_table(seed, P)
-S, s_off = synth.modalias_strings(seed + 3, P, N)
+S, s_off = synth.modalias_strings(int(os.environ.get("CENSUS_STRING_SEED", seed + 3)), P, N)
 d = "/tmp/k1census"
 os.makedirs(d, exist_ok=True)
 for name, arr in (("A", A), ("ao", a_off), ("S", S), ("so", s_off)):

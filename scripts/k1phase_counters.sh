@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ instruction counters of the tile kernel with its phases cut off one after the other
 # (variant builds libmontecarlo_k1skip<n>.so under scripts/_bin): per-phase instruction counts
-# follow by subtraction.  Output: gpurun_out/k1phase/<n>.csv rows "counter value".
+# and times follow by subtraction (scripts/k1phase_table.py prints the table).
 set -u
 OUT=gpurun_out/k1phase
 mkdir -p "$OUT"
@@ -22,4 +22,6 @@ for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 print("skip", k, {c: sorted(v)[len(v) // 2] for c, v in sorted(vals.items())})
 PY
+    MONTECARLO_LIB=$lib K1_REPS=30,30 timeout -k 10 120 python3 scripts/k1time.py > "$OUT/time$k.log" 2>&1 || exit 1
 done
+python3 scripts/k1phase_table.py
