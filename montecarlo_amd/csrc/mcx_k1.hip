@@ -1209,12 +1209,27 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                     break; /* the same for the whole wave */
                 bool found = false;
                 uint32_t fstart = 0, fcnt = 0;
+                /* nearly every walk ends inside the first word of tags, with at most one entry to
+                 * look at: that case runs straight through, the others loop behind it */
+                bool walk_on = false;
+                uint32_t t4 = tag[i], cand = 0, p = h[i] & T.sub_mask;
+                const uint32_t tg = mcx_key_tag(h[i]) * 0x01010101u, gid = key[i] >> 6;
                 if (act[i]) {
-                    const uint32_t tg = mcx_key_tag(h[i]) * 0x01010101u, gid = key[i] >> 6;
-                    uint32_t t4 = tag[i];
-                    for (uint32_t p = h[i] & T.sub_mask;; p = (p + 4u) & T.sub_mask, t4 = k1_tags4(T.sub_tags, p)) {
-                        const uint32_t empty = k1_zero_bytes(t4);
-                        uint32_t cand = k1_zero_bytes(t4 ^ tg) & k1_below_lowest(empty);
+                    const uint32_t empty = k1_zero_bytes(t4);
+                    cand = k1_zero_bytes(t4 ^ tg) & k1_below_lowest(empty);
+                    if (cand != 0u) {
+                        const mcx_sub_t en = T.sub[(p + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.sub_mask];
+                        cand &= cand - 1u;
+                        if (en.gram == w[i] && en.gid == gid) {
+                            found = true;
+                            fstart = en.start;
+                            fcnt = en.count;
+                        }
+                    }
+                    walk_on = !found && (cand != 0u || empty == 0u);
+                }
+                if (__ballot(walk_on) != 0ull && walk_on) {
+                    for (;;) {
                         while (cand != 0u && !found) {
                             const mcx_sub_t en = T.sub[(p + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.sub_mask];
                             cand &= cand - 1u;
@@ -1224,8 +1239,11 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                                 fcnt = en.count;
                             }
                         }
-                        if (found || empty != 0u)
+                        if (found || k1_zero_bytes(t4) != 0u)
                             break;
+                        p = (p + 4u) & T.sub_mask;
+                        t4 = k1_tags4(T.sub_tags, p);
+                        cand = k1_zero_bytes(t4 ^ tg) & k1_below_lowest(k1_zero_bytes(t4));
                     }
                 }
                 /* a gram that occurs twice in the string names its run once.  The lanes that

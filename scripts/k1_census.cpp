@@ -57,6 +57,7 @@ int main(int argc, char **argv)
     std::map<uint64_t, uint64_t> cost_hist;
     std::vector<uint32_t> tile_cost; /* run lengths of the survivors of the current tile of 64 strings, in order */
     uint64_t wave_sum = 0, wave_max64 = 0;
+    uint32_t big_shown = 0;
     for (uint32_t i = 0; i < N; ++i) {
         if (i % 64 == 0 || i == N - 1) {
             /* a lane per survivor, 64 to a wave: a wave takes as long as its longest run */
@@ -101,6 +102,14 @@ int main(int argc, char **argv)
                     }
                 } else runs.push_back({sl.start, sl.count});
                 for (auto r : runs) {
+                    if (getenv("CENSUS_BIGRUNS") && r.second > 64 && big_shown < 12) {
+                        ++big_shown;
+                        printf("  run of %u for %.*s:\n", r.second, (int)len, (const char *)S.data() + s_off[i]);
+                        for (uint32_t k = r.first; k < r.first + r.second; k += r.second / 6) {
+                            const uint32_t *sl2 = &t.slot[(size_t)k * MCX_SLOT_WORDS];
+                            printf("      %.*s\n", (int)(a_off[sl2[1] + 1] - a_off[sl2[1]]), (const char *)A.data() + a_off[sl2[1]]);
+                        }
+                    }
                     cand += r.second;
                     uint32_t bucket = 1;
                     while (bucket < r.second) bucket *= 2;
