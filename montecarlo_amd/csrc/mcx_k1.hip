@@ -1779,7 +1779,7 @@ static bool k1_use_tiles(const mcx_ctx *ctx, uint32_t N)
 {
     if (ctx->bulk_min_set)
         return N >= ctx->bulk_min;
-    if (N >= 7168u)
+    if (N >= 8704u)
         return true;
     /* the larger the largest group, the earlier the second index pays: any batch from 8192
      * patterns in one group on */
@@ -1812,8 +1812,10 @@ static int launch_alias_match(mcx_ctx *ctx, const uint8_t *d_S, const uint32_t *
     k1_table_t T;
     k1_fill_table(ctx, T);
     const uint32_t s_aligned = ((uintptr_t)d_S & 3u) == 0u ? 1u : 0u;
-    /* few strings: one per block, so that the whole chip has work; many: more per block */
-    uint32_t spb = (N + 2047u) / 2048u;
+    /* up to 1024 blocks, four to a CU: a block's time is mostly its chain of dependent loads, and a
+     * second string costs it a tenth more, while a fifth block per CU costs every block of that CU
+     * (2000 strings: 12.8 us as 1000 blocks of two, 18.4 us as 2000 blocks of one) */
+    uint32_t spb = (N + 1023u) / 1024u;
 #ifndef MCX_K1_STAMPS
     if (k1_use_tiles(ctx, N)) {
         spb = k1t_strings_per_block(N);
