@@ -95,6 +95,68 @@ fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restri
     }
 }
 
+/*
+ * The same result by word column: a block owns the 32 hosts of one word of every row, takes
+ * their devices (consecutive in the arrays) and ORs the host bits into a column of V words in
+ * LDS; then it stores the words that are not 0 (the matrices start out zeroed).  The devices of
+ * 32 hosts name a few hundred modules between them, so a column costs a few hundred plain
+ * stores instead of one atomic per device on a row 4 * HW bytes from the next.
+ * Dynamic LDS: V words, twice that with bound_mod (a column of U and one of L).
+ */
+#define FL_COL_LDS_MAX 65536u
+__global__ void __launch_bounds__(FL_THREADS)
+fl_scatter_cols(const uint32_t *__restrict__ first_idx, const uint32_t *__restrict__ a_mod,
+                const uint32_t *__restrict__ bound_mod, uint32_t N, const uint32_t *__restrict__ dev_off,
+                uint32_t H, uint32_t V, uint32_t HW, uint32_t *__restrict__ U, uint32_t *__restrict__ L)
+{
+    extern __shared__ uint32_t fl_col[];
+    __shared__ uint32_t hoff[33];
+    uint32_t *ucol = fl_col, *lcol = fl_col + V;
+    const uint32_t w = blockIdx.x, h0 = 32u * w, nh = min(32u, H - h0);
+    if (threadIdx.x <= nh)
+        hoff[threadIdx.x] = dev_off[h0 + threadIdx.x];
+    for (uint32_t v = threadIdx.x; v < (bound_mod ? 2u * V : V); v += FL_THREADS)
+        fl_col[v] = 0u;
+    __syncthreads();
+    const uint32_t i0 = hoff[0], i1 = min(hoff[nh], N); /* the offsets are the caller's: stay inside the arrays */
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += FL_THREADS) {
+        const uint32_t j = first_idx[i];
+        const uint32_t m = j == MCX_NO_MATCH ? MCX_NO_MATCH : a_mod[j];
+        const uint32_t b = bound_mod ? bound_mod[i] : MCX_NO_MATCH;
+        if (m >= V && b >= V)
+            continue;
+        /* largest k < nh with hoff[k] <= i */
+        uint32_t lo = 0, hi = nh;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (hoff[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t bit = 1u << lo;
+        if (!bound_mod) {
+            atomicOr(&ucol[m], bit); /* used = resolved */
+        } else {
+            if (m < V)
+                atomicOr(&lcol[m], bit); /* resolved: loaded, like a module loaded by hand */
+            if (b < V)
+                atomicOr(&ucol[b], bit); /* used = bound */
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < V; v += FL_THREADS) {
+        const uint32_t u = ucol[v];
+        if (u != 0u)
+            U[(size_t)v * HW + w] = u;
+        if (bound_mod) {
+            const uint32_t l = lcol[v];
+            if (l != 0u)
+                L[(size_t)v * HW + w] = l;
+        }
+    }
+}
+
 /* one thread per entry of the hosts' extra-module lists: L[module][host] */
 __global__ void __launch_bounds__(FL_THREADS)
 fl_scatter_extra(const uint32_t *__restrict__ extra_off, const uint32_t *__restrict__ extra_ids, uint32_t X,
@@ -285,8 +347,14 @@ static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_of
     if (N) {
         if ((rc = mcx_alias_match_dev(ctx, d_S, d_s_off, N, d_first, d_count)) != MCX_OK)
             return rc;
-        fl_scatter_used<<<(N + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
-            d_first, ctx->d_amod, (const uint32_t *)d_bound_mod, N, (const uint32_t *)d_dev_off, H, V, HW, U, L);
+        const size_t col_lds = 4 * (size_t)V * (d_bound_mod ? 2 : 1);
+        if (col_lds <= FL_COL_LDS_MAX)
+            fl_scatter_cols<<<HW, FL_THREADS, col_lds, ctx->stream>>>(d_first, ctx->d_amod,
+                                                                      (const uint32_t *)d_bound_mod, N,
+                                                                      (const uint32_t *)d_dev_off, H, V, HW, U, L);
+        else
+            fl_scatter_used<<<(N + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+                d_first, ctx->d_amod, (const uint32_t *)d_bound_mod, N, (const uint32_t *)d_dev_off, H, V, HW, U, L);
     }
     if (X)
         fl_scatter_extra<<<(X + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
