@@ -64,6 +64,7 @@ void mcx_free_graph(mcx_ctx *ctx)
     (void)hipFree(ctx->d_lvl_order);
     ctx->d_lvl_order = nullptr;
     ctx->lvl_ptr.clear();
+    ctx->lvl_maxdeg.clear();
     ctx->d_rowptr = ctx->d_col = ctx->d_rrowptr = ctx->d_rcol = ctx->d_part = ctx->d_bfs = nullptr;
     ctx->d_queue[0] = ctx->d_queue[1] = nullptr;
     ctx->n_part = 0;

@@ -210,6 +210,52 @@ fl_level(const uint32_t *__restrict__ order, uint32_t n_rows, const uint32_t *__
 }
 
 /*
+ * The same for a level of few modules with many holders each (the core modules at the end of the
+ * order: one row, thousands of holders): a block per module and 64 word columns, wave s of the
+ * block ORs the s-th part of the holder list, the parts meet in LDS and wave 0 writes the row.
+ * The one-thread-per-word kernel would walk such a list with 3000 threads on the whole chip.
+ */
+#define FLS_MAX 16u
+__global__ void __launch_bounds__(64 * FLS_MAX)
+fl_level_sliced(const uint32_t *__restrict__ order, uint32_t n_rows, const uint32_t *__restrict__ rrowptr,
+                const uint32_t *__restrict__ rcol, const uint8_t *__restrict__ safe_name,
+                const uint8_t *__restrict__ hw_alias, uint32_t HW, uint32_t chunks, uint32_t *U, uint32_t *L)
+{
+    __shared__ uint32_t part[FLS_MAX][64];
+    const uint32_t c = threadIdx.x & 63u, s = threadIdx.x >> 6, slices = blockDim.x >> 6;
+    const uint32_t row = blockIdx.x / chunks, w = (blockIdx.x - row * chunks) * 64u + c;
+    const uint32_t v = order[row];
+    const uint32_t e0 = rrowptr[v], n = rrowptr[v + 1] - e0, per = (n + slices - 1u) / slices;
+    uint32_t e = min(n, s * per) + e0;
+    const uint32_t e1 = min(n, s * per + per) + e0;
+    uint32_t hold = 0;
+    if (w < HW) {
+        for (; e + 8u <= e1; e += 8u) {
+            uint32_t u[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k)
+                u[k] = rcol[e + k];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k)
+                hold |= L[(size_t)u[k] * HW + w];
+        }
+        for (; e < e1; ++e)
+            hold |= L[(size_t)rcol[e] * HW + w];
+    }
+    part[s][c] = hold;
+    __syncthreads();
+    if (s != 0u || w >= HW)
+        return;
+    for (uint32_t k = 1; k < slices; ++k)
+        hold |= part[k][c];
+    const size_t at = (size_t)v * HW + w;
+    const uint32_t used = U[at];
+    const uint32_t loaded = used | L[at] | hold;
+    L[at] = loaded;
+    U[at] = (safe_name[v] && hw_alias[v]) ? (loaded & ~used & ~hold) : 0u;
+}
+
+/*
  * R -> per-host lists.  One thread per word column of R (32 hosts) and row
  * segment (FLC_SEGS segments of consecutive modules): a column alone would be
  * H / 32 threads for the whole matrix.  A thread walks its rows in ascending
@@ -367,9 +413,19 @@ static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_of
             ctx->err = "fleet too large for one launch: split the fleet into groups of hosts";
             return MCX_E_TOO_LARGE;
         }
-        fl_level<<<(uint32_t)blocks, FL_THREADS, 0, ctx->stream>>>(ctx->d_lvl_order + r0, n_rows, ctx->d_rrowptr,
-                                                                  ctx->d_rcol, (const uint8_t *)d_safe_name, d_hw,
-                                                                  HW, U, L);
+        /* few threads and long holder lists: the lists are cut into parts of 32 holders or more */
+        uint32_t slices = 1;
+        while (slices < FLS_MAX && threads * slices < 400000ull && ctx->lvl_maxdeg[k] >= 64u * slices)
+            slices *= 2u;
+        const uint32_t chunks = (HW + 63u) / 64u;
+        if (slices > 1u && (uint64_t)n_rows * chunks <= 0x7FFFFFFFull)
+            fl_level_sliced<<<n_rows * chunks, 64u * slices, 0, ctx->stream>>>(
+                ctx->d_lvl_order + r0, n_rows, ctx->d_rrowptr, ctx->d_rcol, (const uint8_t *)d_safe_name, d_hw, HW,
+                chunks, U, L);
+        else
+            fl_level<<<(uint32_t)blocks, FL_THREADS, 0, ctx->stream>>>(ctx->d_lvl_order + r0, n_rows, ctx->d_rrowptr,
+                                                                      ctx->d_rcol, (const uint8_t *)d_safe_name, d_hw,
+                                                                      HW, U, L);
     }
     fl_columns<false><<<col_grid, FLC_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_seg, nullptr, nullptr);
     fl_seg_prefix<<<(H + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(d_seg, H, d_cnt);

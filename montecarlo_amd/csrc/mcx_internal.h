@@ -82,6 +82,7 @@ struct mcx_ctx {
      * Empty lvl_ptr: the graph has a cycle and has no such order. */
     uint32_t *d_lvl_order = nullptr;
     std::vector<uint32_t> lvl_ptr;
+    std::vector<uint32_t> lvl_maxdeg; /* per level: the most holders one of its modules has */
 
     /* staging of the host-buffer alias match, grown on demand */
     void *d_io = nullptr;

@@ -1070,7 +1070,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     }
     /* holder levels (Kahn over "u needs v": v follows all of its holders);
      * a graph with a cycle has none and only the fleet pipeline minds */
-    std::vector<uint32_t> order, lvl_ptr;
+    std::vector<uint32_t> order, lvl_ptr, lvl_maxdeg;
     {
         std::vector<uint32_t> waiting((size_t)V), level((size_t)V, 0);
         order.reserve(V);
@@ -1102,6 +1102,12 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
             std::vector<uint32_t> at(lvl_ptr.begin(), lvl_ptr.end() - 1);
             for (uint32_t v = 0; v < V; ++v)
                 order[at[level[v]]++] = v;
+            lvl_maxdeg.assign(nl, 0);
+            for (uint32_t v = 0; v < V; ++v) {
+                const uint32_t deg = rrow[(size_t)v + 1] - rrow[v];
+                if (deg > lvl_maxdeg[level[v]])
+                    lvl_maxdeg[level[v]] = deg;
+            }
         } else {
             order.clear();
         }
@@ -1231,6 +1237,7 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
     ctx->E = E;
     ctx->n_part = (uint32_t)part.size() - 1u;
     ctx->lvl_ptr = lvl_ptr;
+    ctx->lvl_maxdeg = lvl_maxdeg;
     ctx->n_slices = (uint32_t)slices.size();
     ctx->pk_bits = pk_bits;
     ctx->cu_rows_max = cu_rows_max;
