@@ -129,8 +129,9 @@ int mcx_alias_match_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
  * in file order).  CSR output: list_off[i] .. list_off[i+1] index list_idx;
  * with K > 0 only the first K positions of a string are kept (K = 0: all).
  * *total_out = list_off[N]; when list_idx (cap entries) is too small the call
- * returns MCX_E_TOO_LARGE with *total_out and list_off filled in.  Costs two
- * passes of the match (count, then fill).  Strings that kmod would refuse
+ * returns MCX_E_TOO_LARGE with *total_out and list_off filled in.  Costs one
+ * pass of the match and a few small launches (a second pass only when some
+ * string is matched by more than 16 distinct pattern texts).  Strings that kmod would refuse
  * (MCX_TABLE_NORMALIZE_DASH tables) have empty lists.
  */
 int mcx_alias_match_list(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, uint32_t K,
