@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 NO_MATCH = 0xFFFFFFFF
 
 
-def make_fleet(seed, P, H, mean_dev, max_extra, mean_deg=4):
+def make_fleet(seed, P, H, mean_dev, max_extra, mean_deg=4, V=None):
     A, a_off, a_mod = synth.alias_table(seed, P)
-    V = synth.alias_modules(P)
+    V = synth.alias_modules(P) if V is None else V  # more modules than the aliases name: extras reach them
     rowptr, col = synth.dep_graph(seed + 1, V, mean_deg)
     dev_cnt, extra_off, extra_ids = synth.fleet_hosts(seed + 2, V, H, mean_dev, max_extra)
     dev_off = np.zeros(H + 1, dtype=np.uint32)
@@ -56,6 +56,28 @@ def test_fleet_vs_oracle(gpu_ctx, oracle_mod, seed, P, H, mean_dev, max_extra):
     assert np.array_equal(off, w_off)
     assert np.array_equal(ids, w_ids)
     assert len(ids) > 0 or H == 1
+
+
+@pytest.mark.parametrize("V", [10000, 20000])
+def test_fleet_many_modules(gpu_ctx, oracle_mod, V):
+    """module counts around the sizes at which the used-driver bits stop being built by word
+    column in LDS (one column of V words, two with bound drivers: 64 KB) and go back to one
+    atomic per device: both modes against the oracle on either side"""
+    f = make_fleet(91, 3000, 300, 10, 6, V=V)
+    assert f["V"] == V and int(f["extra_ids"].max()) > synth.alias_modules(3000)
+    off, ids = run_fleet(gpu_ctx, f)
+    w_off, w_ids = oracle_fleet(oracle_mod, gpu_ctx, f)
+    assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids) and len(ids) > 0
+    first, _ = oracle_mod.alias_match(f["A"], f["a_off"], f["S"], f["s_off"])
+    resolved = np.where(first != NO_MATCH, f["a_mod"][np.minimum(first, len(f["a_mod"]) - 1)], NO_MATCH).astype(np.uint32)
+    bound = resolved.copy()
+    bound[::3] = NO_MATCH  # every third device has no driver bound
+    hw = oracle_mod.hw_alias_flags(f["A"], f["a_off"], f["a_mod"], f["V"])
+    b_off, b_ids = oracle_mod.fleet_roots(f["rowptr"], f["col"], resolved, f["dev_off"], f["extra_off"],
+                                          f["extra_ids"], f["safe"], hw, bound_mod=bound)
+    off, ids = gpu_ctx.fleet_roots_bound(f["S"], f["s_off"], f["dev_off"], f["extra_off"], f["extra_ids"], f["safe"],
+                                         bound)
+    assert np.array_equal(off, b_off) and np.array_equal(ids, b_ids) and len(ids) > len(w_ids)
 
 
 def test_fleet_edge_cases(gpu_ctx, oracle_mod):
