@@ -58,7 +58,11 @@ int main(int argc, char **argv)
     std::vector<uint32_t> tile_cost; /* run lengths of the survivors of the current tile of 64 strings, in order */
     uint64_t wave_sum = 0, wave_max64 = 0;
     uint32_t big_shown = 0;
+    uint64_t surv_before = 0;
     for (uint32_t i = 0; i < N; ++i) {
+        if (getenv("CENSUS_GREP") && i > 0 && strstr((const char *)S.data() + s_off[i - 1], getenv("CENSUS_GREP")) == (const char *)S.data() + s_off[i - 1])
+            printf("  string %u: %llu survivors\n", i - 1, (unsigned long long)(surv - surv_before));
+        surv_before = surv;
         if (i % 64 == 0 || i == N - 1) {
             /* a lane per survivor, 64 to a wave: a wave takes as long as its longest run */
             for (size_t a = 0; a < tile_cost.size(); a += 64) {
@@ -131,7 +135,7 @@ int main(int argc, char **argv)
                         if (ok) ++match;
                         else if (fp_shape.size() < 100000) {
                             std::string p((const char *)A.data() + a_off[slot[1]], a_off[slot[1] + 1] - a_off[slot[1]]);
-                            if (getenv("CENSUS_EXAMPLES") && i < 40)
+                            if (getenv("CENSUS_EXAMPLES") && (i < 40 || (getenv("CENSUS_GREP") && strstr((const char *)S.data() + s_off[i], getenv("CENSUS_GREP")) == (const char *)S.data() + s_off[i])))
                                 printf("  miss: %s  vs  %.*s\n", p.c_str(), (int)len, (const char *)S.data() + s_off[i]);
                             /* shape: digits/hex replaced */
                             for (auto &c : p) if ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'F')) c = 'X';
