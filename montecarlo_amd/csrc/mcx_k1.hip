@@ -1779,7 +1779,7 @@ static bool k1_use_tiles(const mcx_ctx *ctx, uint32_t N)
 {
     if (ctx->bulk_min_set)
         return N >= ctx->bulk_min;
-    if (N >= 8704u)
+    if (N > 8192u) /* beyond 1024 blocks of eight strings the small-batch kernel needs a second round */
         return true;
     /* the larger the largest group, the earlier the second index pays: any batch from 8192
      * patterns in one group on */
