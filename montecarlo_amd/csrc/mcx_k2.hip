@@ -1484,7 +1484,11 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
             }
             for (uint32_t b = 0; b < batch; ++b) {
                 const uint32_t level = base + b;
-                if (b != 0u && b % K2B_SMALL_EVERY == 0u)
+                /* not before the level at which the last search in this direction had become
+                 * short again, less one: while the frontier is large that launch only looks and
+                 * returns (a search that shrinks earlier than the last one runs its short levels
+                 * as launches of their own until then) */
+                if (b != 0u && b % K2B_SMALL_EVERY == 0u && level + 1u >= hint)
                     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[level & 1u],
                                                                   queue[(level + 1u) & 1u], st, level, none, 0u);
                 k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, queue[level & 1u],
