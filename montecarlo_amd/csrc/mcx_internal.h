@@ -170,6 +170,31 @@ static inline int mcx_wait_seq(mcx_ctx *ctx, uint32_t want)
     return 0;
 }
 
+/* The same for two kernels of which either may be the one that has the answer: returns as soon as
+ * the word holds `early` or `last` (the kernel storing `last` runs behind the other, so after the
+ * fallback synchronisation the word holds `last`). */
+static inline int mcx_wait_seq2(mcx_ctx *ctx, uint32_t early, uint32_t last)
+{
+    volatile uint32_t *seq = ctx->h_pinned + MCX_PINNED_SEQ_WORD;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        const uint32_t now = *seq;
+        if (now == early || now == last) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return 0;
+        }
+        if ((spins & 63u) == 63u &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200))
+            break;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*seq != last) {
+        ctx->err = "read-back kernel did not finish";
+        return MCX_E_HIP;
+    }
+    return 0;
+}
+
 static inline size_t up256(size_t x)
 {
     return (x + 255) & ~(size_t)255;

@@ -28,6 +28,7 @@
 #ifndef K2B_BLOCKS
 #define K2B_BLOCKS 1024u  /* grid of one BFS level; strides over the frontier */
 #endif
+#define K2B_PINNED_END 44u /* six words of the pinned read-back area: see k2b_small's only_the_end */
 #define K2B_BATCH 16u     /* most levels enqueued between two looks at the queue sizes */
 #define K2B_MAX_LEVELS 64u   /* window of per-level counters, reused by deeper searches */
 
@@ -805,7 +806,7 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
 __global__ void __launch_bounds__(K2S_THREADS)
 k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, uint32_t *__restrict__ out,
           uint2 *__restrict__ queue, uint2 *__restrict__ spill, k2b_state_t st, uint32_t level, k2b_report_t rep,
-          uint32_t seq)
+          uint32_t seq, uint32_t only_the_end)
 {
     __shared__ uint32_t qb[2][K2S_CAP], qe[2][K2S_CAP]; /* list start, list end */
     __shared__ uint32_t pre[K2S_CAP + 1u];               /* exclusive sums of the list lengths */
@@ -959,16 +960,22 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
         const uint32_t handed = (left_q != 0u || left_h != 0u) ? 1u : 0u;
         st.cnt[K2B_W_HANDOVER] = handed;
         unsigned long long edges = scanned ? atomicAdd(st.edges, scanned) + scanned : *st.edges;
-        if (seq) {
-            rep.sizes[0] = left_q;
-            rep.sizes[1] = left_h;
+        /* only_the_end: one of a batch of launches - it reports (into words of its own) if the
+         * search ends here, with the level it was launched for and the sequence number twice, so
+         * that a host that looks later, when the batch's own report has come in, still sees
+         * who ended the search */
+        /* (a launch that found the search over already leaves the word to the batch's report) */
+        const bool tell = seq != 0u && (only_the_end == 0u || (handed == 0u && mine));
+        if (tell) {
+            rep.sizes[0] = only_the_end ? level : left_q;
+            rep.sizes[1] = only_the_end ? seq : left_h;
             *rep.edges = edges;
             rep.small[0] = small_levels;
             rep.small[1] = handed;
             __threadfence_system();
             __hip_atomic_store(rep.seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        wsum[0] = (seq && !handed) ? 1u : 0u; /* the search is over and the host has been told: clear the state */
+        wsum[0] = (tell && !handed) ? 1u : 0u; /* the search is over and the host has been told: clear the state */
     }
     __syncthreads();
     if (wsum[0])
@@ -1449,11 +1456,15 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
      * then enqueued without a look in between. */
     const bool expect_handover = ctx->bfs_depth[direction] != 0u;
     const uint32_t seq0 = expect_handover ? 0u : mcx_next_seq(ctx);
-    k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[0], queue[1], st, 0u, rep, seq0);
+    k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[0], queue[1], st, 0u, rep, seq0,
+                                                  0u);
     HIPCHK(ctx, hipGetLastError());
     if (!expect_handover && mcx_wait_seq(ctx, seq0))
         return MCX_E_HIP;
     uint32_t lv = 0;
+    bool ended_early = false; /* the totals then come from the words of the launch that ended the search */
+    unsigned long long ended_edges = 0;
+    uint32_t ended_small = 0;
     if (expect_handover || h_small[1] != 0u) {
         /* a launch per level from here, with the one-workgroup kernel in front of every second
          * level (it returns at once while the frontier is large, and takes the rest of the
@@ -1468,7 +1479,14 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
         batch = (batch + 1u) & ~1u;
         uint32_t base = 0; /* level of the counter window the next batch starts at */
         bool done = false;
-        k2b_report_t none = {};
+        /* where a one-workgroup launch inside a batch reports the end of the search (the batch's
+         * own report comes a few launches later and would read a state that launch has cleared) */
+        uint32_t *h_end = ctx->h_pinned + K2B_PINNED_END;
+        k2b_report_t end_rep;
+        end_rep.sizes = d_sizes + K2B_PINNED_END;
+        end_rep.edges = (unsigned long long *)(d_sizes + K2B_PINNED_END + 2u);
+        end_rep.small = d_sizes + K2B_PINNED_END + 4u;
+        end_rep.seq = rep.seq;
         /* Towards the dependencies every list leads to the same few modules everything needs:
          * at the start of a level each wave still sees them open and claims them, and claims
          * on one cache line are served one after the other - the first step of such a level
@@ -1482,6 +1500,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                 k2b_rewind<<<1, 256, 0, ctx->stream>>>(st.cnt, base);
                 base = 0;
             }
+            const uint32_t seq_end = mcx_next_seq(ctx);
             for (uint32_t b = 0; b < batch; ++b) {
                 const uint32_t level = base + b;
                 /* not before the level at which the last search in this direction had become
@@ -1490,7 +1509,8 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                  * as launches of their own until then) */
                 if (b != 0u && b % K2B_SMALL_EVERY == 0u && level + 1u >= hint)
                     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[level & 1u],
-                                                                  queue[(level + 1u) & 1u], st, level, none, 0u);
+                                                                  queue[(level + 1u) & 1u], st, level, end_rep, seq_end,
+                                                                  1u);
                 k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, queue[level & 1u],
                                                                       (uint32_t *)d_out_bitmap,
                                                                       queue[(level + 1u) & 1u], st, level, sweep_waves);
@@ -1498,8 +1518,17 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
             HIPCHK(ctx, hipGetLastError());
             k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, rep, mcx_next_seq(ctx));
             HIPCHK(ctx, hipGetLastError());
-            if (mcx_wait_seq(ctx, ctx->pinned_seq))
+            if (mcx_wait_seq2(ctx, seq_end, ctx->pinned_seq))
                 return MCX_E_HIP;
+            if (h_end[1] == seq_end) {
+                /* a one-workgroup launch of this batch ended the search: every level before the
+                 * one it was launched for had a frontier */
+                lv += h_end[0] - base;
+                ended_edges = *(const unsigned long long *)(h_end + 2);
+                ended_small = h_end[4];
+                ended_early = true;
+                break;
+            }
             for (uint32_t b = 0; b < batch; ++b) {
                 if (sizes[2u * b] == 0u && sizes[2u * b + 1u] == 0u) {
                     done = true;
@@ -1514,9 +1543,9 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     }
     ctx->bfs_clean = true;
     if (edges_scanned)
-        *edges_scanned = *h_edges;
+        *edges_scanned = ended_early ? ended_edges : *h_edges;
     if (levels)
-        *levels = h_small[0] + lv;
+        *levels = (ended_early ? ended_small : h_small[0]) + lv;
     return MCX_OK;
 }
 
