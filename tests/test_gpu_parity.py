@@ -271,10 +271,11 @@ def test_k1_second_index_of_large_groups(gpu_ctx, oracle_mod, monkeypatch, sub_m
     assert np.array_equal(idx[: off[60]], o_idx)
 
 
-@pytest.mark.parametrize("N", [1, 100, 2049, 5000, 12000])
+@pytest.mark.parametrize("N", [1, 100, 2049, 5000, 8000, 12000])
 def test_k1_large_batch_kernel_on_small_batches(gpu_ctx, oracle_mod, monkeypatch, N):
     """A table with a very large group sends every batch to the large-batch kernel; here
-    the batch-size seam does, so that it runs with one to six strings per block."""
+    the batch-size seam does, so that it runs with one to eight strings per block (and the
+    small-batch kernel, which answers second, with one to eight as well)."""
     monkeypatch.setenv("MCX_BULK_MIN", "1")
     monkeypatch.setenv("MCX_SUB_MIN", "5")
     P = 20000
