@@ -916,7 +916,7 @@ static_assert(K1T_DEDUP_CELLS * K1T_WAVES <= K1T_RCAP, "the second index borrows
  * nearly every string follow from those without a second pass.  MODE 2: every match is written
  * into L.idx at the place L.off (the exclusive sums of a counting pass) gives its string. */
 #define K1T_LIST_CAP 16u
-#define K1_EMIT_NARROW 8u /* lists up to this length are written by one thread, longer ones by a wave */
+#define K1_EMIT_NARROW 4u /* lists up to this length are written by one thread, longer ones by sixteen lanes */
 
 template <int MODE>
 __global__ void __launch_bounds__(K1T_THREADS, K1T_MIN_WAVES)
@@ -1512,10 +1512,13 @@ k1_list_sort_long(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__rest
 
 /*
  * The same for the strings with longer lists (a pattern text with dozens of copies in the
- * table), a wave per string: every table position of every run computes its own place in
- * the merged list - its place in its run plus, for each other run, the number of entries
+ * table), sixteen lanes per string: every table position of every run computes its own place
+ * in the merged list - its place in its run plus, for each other run, the number of entries
  * below it (bisection) - and is written there if that place is inside the list.
  */
+#define K1_WIDE_LANES 16u
+#define K1_WIDE_ALL 96u /* entries of a list that are ranked against each other in LDS */
+static_assert(K1_WIDE_LANES >= K1T_LIST_CAP, "a lane per matching text");
 __global__ void __launch_bounds__(256)
 k1_list_emit_wide(const uint32_t *__restrict__ nslots, const uint32_t *__restrict__ slots,
                   const uint32_t *__restrict__ slot_tab, const uint32_t *__restrict__ dup_start,
@@ -1524,54 +1527,83 @@ k1_list_emit_wide(const uint32_t *__restrict__ nslots, const uint32_t *__restric
 {
     if (totals[0] > cap || totals[0] > 0xFFFFFFFFull || totals[1] != 0ull)
         return; /* as in k1_list_emit */
-    __shared__ const uint32_t *rptr[4][K1T_LIST_CAP];
-    __shared__ uint32_t rlen[4][K1T_LIST_CAP], rhead[4][K1T_LIST_CAP], rbase[4][K1T_LIST_CAP + 1u];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t i = blockIdx.x * 4u + wave;
-    if (i >= N)
-        return;
-    const uint32_t ns = nslots[i], want = off[i + 1] - off[i];
-    if (ns > K1T_LIST_CAP || want <= K1_EMIT_NARROW)
-        return; /* the same for the whole wave */
-    if (lane < ns) {
-        const uint32_t kk = slots[(size_t)i * K1T_LIST_CAP + lane];
+    constexpr uint32_t GROUPS = 256u / K1_WIDE_LANES;
+    __shared__ uint32_t rat[GROUPS][K1T_LIST_CAP]; /* start of the run in dup_idx */
+    __shared__ uint32_t all[GROUPS][K1_WIDE_ALL];
+    __shared__ uint32_t rlen[GROUPS][K1T_LIST_CAP], rhead[GROUPS][K1T_LIST_CAP], rbase[GROUPS][K1T_LIST_CAP + 1u];
+    const uint32_t g = threadIdx.x / K1_WIDE_LANES, l = threadIdx.x % K1_WIDE_LANES;
+    const uint32_t i = blockIdx.x * GROUPS + g;
+    /* the lanes of a group stay together through the wave-wide barriers below: no early return */
+    const uint32_t ns = i < N ? nslots[i] : 0u, want = i < N ? off[i + 1] - off[i] : 0u;
+    const bool mine = i < N && ns <= K1T_LIST_CAP && want > K1_EMIT_NARROW;
+    if (mine && l < ns) {
+        const uint32_t kk = slots[(size_t)i * K1T_LIST_CAP + l];
         const uint32_t *sp = slot_tab + (size_t)kk * MCX_SLOT_WORDS;
         const uint32_t mult = sp[MCX_SLOT_MULT];
-        rlen[wave][lane] = mult;
-        rptr[wave][lane] = mult > 1u ? dup_idx + dup_start[kk] : nullptr;
-        rhead[wave][lane] = sp[1];
+        rlen[g][l] = mult;
+        rat[g][l] = mult > 1u ? dup_start[kk] : 0u;
+        rhead[g][l] = sp[1];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0u) {
+    if (mine && l == 0u) {
         uint32_t at = 0;
         for (uint32_t k = 0; k < ns; ++k) {
-            rbase[wave][k] = at;
-            at += rlen[wave][k];
+            rbase[g][k] = at;
+            at += rlen[g][k];
         }
-        rbase[wave][ns] = at;
+        rbase[g][ns] = at;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t total = rbase[wave][ns];
-    uint32_t *dst = idx + off[i];
-    for (uint32_t e = lane; e < total; e += 64u) {
+    const uint32_t total = mine ? rbase[g][ns] : 0u;
+    uint32_t *dst = idx + (mine ? off[i] : 0u);
+    /* a list of up to K1_WIDE_ALL entries (nearly all of them): its entries are gathered into LDS once
+     * and every one is ranked against all the others there - a place in the list is the number of
+     * smaller entries - instead of by bisection through the other runs in global memory, a chain
+     * of dependent loads per entry */
+    const bool small = mine && total <= K1_WIDE_ALL;
+    if (small) {
+        for (uint32_t e = l; e < total; e += K1_WIDE_LANES) {
+            uint32_t r = 0;
+            while (rbase[g][r + 1u] <= e)
+                ++r;
+            all[g][e] = rlen[g][r] > 1u ? dup_idx[rat[g][r] + (e - rbase[g][r])] : rhead[g][r];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (small) {
+        for (uint32_t e = l; e < total; e += K1_WIDE_LANES) {
+            const uint32_t v = all[g][e];
+            uint32_t rank = 0;
+            for (uint32_t o = 0; o < total; ++o)
+                rank += all[g][o] < v ? 1u : 0u; /* table positions are distinct */
+            if (rank < want)
+                dst[rank] = v;
+        }
+        return;
+    }
+    if (!mine)
+        return;
+    for (uint32_t e = l; e < total; e += K1_WIDE_LANES) {
         uint32_t r = 0;
-        while (rbase[wave][r + 1u] <= e)
+        while (rbase[g][r + 1u] <= e)
             ++r;
-        const uint32_t p = e - rbase[wave][r];
-        const uint32_t v = rlen[wave][r] > 1u ? rptr[wave][r][p] : rhead[wave][r];
+        const uint32_t p = e - rbase[g][r];
+        const uint32_t v = rlen[g][r] > 1u ? dup_idx[rat[g][r] + p] : rhead[g][r];
         uint32_t rank = p;
         for (uint32_t o = 0; o < ns; ++o) {
             if (o == r)
                 continue;
-            if (rlen[wave][o] == 1u) {
-                rank += rhead[wave][o] < v ? 1u : 0u;
+            if (rlen[g][o] == 1u) {
+                rank += rhead[g][o] < v ? 1u : 0u;
             } else {
-                const uint32_t *q = rptr[wave][o];
-                uint32_t lo = 0, hi = rlen[wave][o]; /* entries of run o below v */
+                const uint32_t *q = dup_idx + rat[g][o];
+                uint32_t lo = 0, hi = rlen[g][o]; /* entries of run o below v */
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (q[mid] < v)
@@ -2011,7 +2043,7 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
         k1_list_emit<<<grid, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start, ctx->d_dup_idx,
                                                     (const uint32_t *)d_list_off, N, (uint32_t *)d_list_idx, d_total,
                                                     (unsigned long long)cap);
-        k1_list_emit_wide<<<(N + 3u) / 4u, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start,
+        k1_list_emit_wide<<<(N + 256u / K1_WIDE_LANES - 1u) / (256u / K1_WIDE_LANES), 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start,
                                                                  ctx->d_dup_idx, (const uint32_t *)d_list_off, N,
                                                                  (uint32_t *)d_list_idx, d_total,
                                                                  (unsigned long long)cap);
