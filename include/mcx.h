@@ -129,10 +129,13 @@ int mcx_alias_match_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
  * in file order).  CSR output: list_off[i] .. list_off[i+1] index list_idx;
  * with K > 0 only the first K positions of a string are kept (K = 0: all).
  * *total_out = list_off[N]; when list_idx (cap entries) is too small the call
- * returns MCX_E_TOO_LARGE with *total_out and list_off filled in.  Costs one
- * pass of the match and a few small launches (a second pass only when some
+ * returns MCX_E_TOO_LARGE with *total_out and list_off filled in (list_idx then
+ * holds an unspecified part of the lists, never more than cap entries).  Costs
+ * one pass of the match and one more launch (a second pass only when some
  * string is matched by more than 16 distinct pattern texts).  Strings that kmod would refuse
  * (MCX_TABLE_NORMALIZE_DASH tables) have empty lists.
+ * The device call returns as soon as the total is known; list_off and list_idx
+ * are complete in stream order, like the results of every other *_dev call.
  */
 int mcx_alias_match_list(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, uint32_t K,
                          uint32_t *list_off, uint32_t *list_idx, uint64_t cap, uint64_t *total_out);

@@ -62,9 +62,15 @@ struct k1_list_t {
     const uint32_t *dup_start; /* per slot: its copies in dup_idx, for slots with a multiplicity above 1 */
     const uint32_t *dup_idx;
     /* short lists (one pass): per string how many distinct pattern texts matched, and the first
-     * K1T_LIST_CAP of their slot numbers, in no particular order */
+     * K1T_LIST_CAP of them, in no particular order: (table position, 1) for a text that stands
+     * once in the table, (slot number, copies) for one that stands there several times */
     uint32_t *nslots;
-    uint32_t *slots;
+    uint2 *texts;
+    /* per tile of the pass: entries its strings' lists hold together (each list cut at K, 0 = whole),
+     * and how many of its strings are matched by more texts than a short list holds */
+    unsigned long long *tile_sum;
+    uint32_t *tile_over;
+    uint32_t K;
 };
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
@@ -916,7 +922,6 @@ static_assert(K1T_DEDUP_CELLS * K1T_WAVES <= K1T_RCAP, "the second index borrows
  * nearly every string follow from those without a second pass.  MODE 2: every match is written
  * into L.idx at the place L.off (the exclusive sums of a counting pass) gives its string. */
 #define K1T_LIST_CAP 16u
-#define K1_EMIT_NARROW 4u /* lists up to this length are written by one thread, longer ones by sixteen lanes */
 
 template <int MODE>
 __global__ void __launch_bounds__(K1T_THREADS, K1T_MIN_WAVES)
@@ -1033,7 +1038,7 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                 /* the short list itself goes straight to global memory: an entry or two per string */
                 const uint32_t at = atomicAdd(&lcount[slot], 1u);
                 if (at < K1T_LIST_CAP)
-                    L.slots[(size_t)(t0 + slot) * K1T_LIST_CAP + at] = kk;
+                    L.texts[(size_t)(t0 + slot) * K1T_LIST_CAP + at] = make_uint2(mult == 1u ? orig : kk, mult);
             }
         }
     };
@@ -1399,55 +1404,26 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                 L.nslots[t0 + i] = refused[i] ? 0u : lcount[i];
         }
     }
-}
-
-/*
- * Match lists from the short lists of a MODE 1 pass, one thread per string.  A matching
- * pattern text stands for one table position, or for several (its copies, ascending in
- * dup_idx): the string's list is the merge of these few ascending runs, cut at `want`
- * entries (the size of the string's place in list_idx).  Strings with more matching
- * texts than a short list holds are left alone (k1_list_cap has counted them).
- */
-__global__ void __launch_bounds__(256)
-k1_list_emit(const uint32_t *__restrict__ nslots, const uint32_t *__restrict__ slots,
-             const uint32_t *__restrict__ slot_tab, const uint32_t *__restrict__ dup_start,
-             const uint32_t *__restrict__ dup_idx, const uint32_t *__restrict__ off, uint32_t N,
-             uint32_t *__restrict__ idx, const unsigned long long *__restrict__ totals, unsigned long long cap)
-{
-    /* enqueued before the host has seen the totals: nothing is written when the lists do not
-     * fit the caller's array or some short list overflowed (the caller then takes another way) */
-    if (totals[0] > cap || totals[0] > 0xFFFFFFFFull || totals[1] != 0ull)
-        return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
-    const uint32_t ns = nslots[i];
-    if (ns > K1T_LIST_CAP)
-        return;
-    const uint32_t want = off[i + 1] - off[i];
-    if (want == 0u || want > K1_EMIT_NARROW)
-        return; /* nothing to write, or k1_list_emit_wide's */
-    const uint32_t *run[K1T_LIST_CAP];
-    uint32_t head[K1T_LIST_CAP], left[K1T_LIST_CAP];
-    for (uint32_t k = 0; k < ns; ++k) {
-        const uint32_t kk = slots[(size_t)i * K1T_LIST_CAP + k];
-        const uint32_t *sp = slot_tab + (size_t)kk * MCX_SLOT_WORDS;
-        const uint32_t mult = sp[MCX_SLOT_MULT];
-        left[k] = mult;
-        run[k] = mult > 1u ? dup_idx + dup_start[kk] : nullptr;
-        head[k] = mult > 1u ? run[k][0] : sp[1];
-    }
-    uint32_t *dst = idx + off[i];
-    for (uint32_t o = 0; o < want; ++o) {
-        uint32_t best = 0, bv = 0xFFFFFFFFu;
-        for (uint32_t k = 0; k < ns; ++k)
-            if (left[k] != 0u && head[k] <= bv) {
-                bv = head[k];
-                best = k;
+    if constexpr (MODE == 1) {
+        if (wave == 0u) {
+            unsigned long long sum = 0;
+            uint32_t over = 0;
+            for (uint32_t i = lane; i < nstr; i += 64u) {
+                if (!refused[i]) {
+                    const uint32_t c = res_count[i];
+                    sum += L.K != 0u && c > L.K ? L.K : c;
+                    over += lcount[i] > K1T_LIST_CAP ? 1u : 0u;
+                }
             }
-        dst[o] = bv;
-        if (--left[best] != 0u)
-            head[best] = *++run[best];
+            for (int d = 32; d > 0; d >>= 1) {
+                sum += __shfl_xor(sum, d);
+                over += __shfl_xor(over, d);
+            }
+            if (lane == 0u) {
+                L.tile_sum[blockIdx.x] = sum;
+                L.tile_over[blockIdx.x] = over;
+            }
+        }
     }
 }
 
@@ -1511,130 +1487,347 @@ k1_list_sort_long(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__rest
 }
 
 /*
- * The same for the strings with longer lists (a pattern text with dozens of copies in the
- * table), sixteen lanes per string: every table position of every run computes its own place
- * in the merged list - its place in its run plus, for each other run, the number of entries
- * below it (bisection) - and is written there if that place is inside the list.
+ * Match lists from the short lists of a MODE 1 pass: one block per tile of the pass.
+ *
+ * Places first.  A string's list starts where the lists of all strings before it end: the
+ * entries of the tiles before this one (tile_sum, added up here by the block itself, or
+ * tile_off when k1_tile_offsets has run) plus those of the tile's earlier strings.  The
+ * last tile's block reports the grand total and the number of overflowed short lists to
+ * the host, which waits for that report and not for the end of the kernel.
+ *
+ * Then the lists.  A matching pattern text stands for one table position, or for several (its
+ * copies, ascending in dup_idx): the list is the merge of these few ascending runs, cut at
+ * `want` entries.  Sixteen lanes per string (four strings after each other) lay the runs out:
+ * running sums of their lengths give every run its place in the list.  The entries of all the
+ * tile's lists then stand side by side in a room in LDS (K1_EMIT_ROOM entries; lists of up to
+ * K1_EMIT_PAIRS entries go there, which is nearly always all of them), a thread per entry: it
+ * finds its list and run, fetches its table position, and counts the smaller entries of its
+ * list - that count is its place.  A list that found no room ranks every entry by bisection
+ * through the other runs in global memory, sixteen lanes per list.  The steps are separated by
+ * barriers of the whole block, so that the loads of a step - for all the block's strings - are
+ * in flight together, and a thread per entry keeps the lanes busy whatever the lists' lengths:
+ * the kernel's time is its instruction count.
+ * Nothing is written past `cap` entries (the caller's array; the host then reports the size that
+ * is needed), and strings with more matching texts than a short list holds are left alone
+ * (another pass fills every list then).
  */
 #define K1_WIDE_LANES 16u
-#define K1_WIDE_ALL 96u /* entries of a list that are ranked against each other in LDS */
-static_assert(K1_WIDE_LANES >= K1T_LIST_CAP, "a lane per matching text");
-__global__ void __launch_bounds__(256)
-k1_list_emit_wide(const uint32_t *__restrict__ nslots, const uint32_t *__restrict__ slots,
-                  const uint32_t *__restrict__ slot_tab, const uint32_t *__restrict__ dup_start,
-                  const uint32_t *__restrict__ dup_idx, const uint32_t *__restrict__ off, uint32_t N,
-                  uint32_t *__restrict__ idx, const unsigned long long *__restrict__ totals, unsigned long long cap)
+#define K1_EMIT_THREADS 256u
+#define K1_EMIT_ROUNDS (K1T_MAX_SPB * K1_WIDE_LANES / K1_EMIT_THREADS)
+#define K1_EMIT_ROOM 1024u /* entries of a tile's lists that are gathered in LDS */
+#define K1_EMIT_SLOTS (K1_EMIT_ROOM / K1_EMIT_THREADS)
+#define K1_EMIT_PAIRS 64u /* lists up to this length: gathered, every entry against every other */
+#define K1_REPORT_BITS 40u /* of a word of the report: the number; above them the call's mark */
+#define K1_TILES_DIRECT 2048u /* up to this many tiles every block adds up the tiles before it by itself */
+static_assert(K1_WIDE_LANES == K1T_LIST_CAP, "a lane per matching text");
+static_assert(K1T_MAX_SPB <= 64u, "the strings of a tile are counted by one wave");
+__global__ void __launch_bounds__(K1_EMIT_THREADS, 6)
+k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restrict__ nslots,
+                   const uint2 *__restrict__ texts, const uint32_t *__restrict__ dup_start,
+                   const uint32_t *__restrict__ dup_idx, uint32_t N, uint32_t spb, uint32_t K,
+                   const unsigned long long *__restrict__ tile_sum, const uint32_t *__restrict__ tile_over,
+                   const unsigned long long *__restrict__ tile_off, uint32_t *__restrict__ off,
+                   uint32_t *__restrict__ idx, unsigned long long cap, unsigned long long *__restrict__ h_totals,
+                   uint32_t seq)
 {
-    if (totals[0] > cap || totals[0] > 0xFFFFFFFFull || totals[1] != 0ull)
-        return; /* as in k1_list_emit */
-    constexpr uint32_t GROUPS = 256u / K1_WIDE_LANES;
-    __shared__ uint32_t rat[GROUPS][K1T_LIST_CAP]; /* start of the run in dup_idx */
-    __shared__ uint32_t all[GROUPS][K1_WIDE_ALL];
-    __shared__ uint32_t rlen[GROUPS][K1T_LIST_CAP], rhead[GROUPS][K1T_LIST_CAP], rbase[GROUPS][K1T_LIST_CAP + 1u];
-    const uint32_t g = threadIdx.x / K1_WIDE_LANES, l = threadIdx.x % K1_WIDE_LANES;
-    const uint32_t i = blockIdx.x * GROUPS + g;
-    /* the lanes of a group stay together through the wave-wide barriers below: no early return */
-    const uint32_t ns = i < N ? nslots[i] : 0u, want = i < N ? off[i + 1] - off[i] : 0u;
-    const bool mine = i < N && ns <= K1T_LIST_CAP && want > K1_EMIT_NARROW;
-    if (mine && l < ns) {
-        const uint32_t kk = slots[(size_t)i * K1T_LIST_CAP + l];
-        const uint32_t *sp = slot_tab + (size_t)kk * MCX_SLOT_WORDS;
-        const uint32_t mult = sp[MCX_SLOT_MULT];
-        rlen[g][l] = mult;
-        rat[g][l] = mult > 1u ? dup_start[kk] : 0u;
-        rhead[g][l] = sp[1];
+    constexpr uint32_t GPR = K1_EMIT_THREADS / K1_WIDE_LANES; /* lists per round */
+    /* sums over the tiles, added up in four cells each: the lanes' addresses differ, so every lane adds
+     * for itself in LDS (with one address the compiler adds the lanes' values up in a scalar loop
+     * first, lane by lane, which costs far more) */
+    __shared__ unsigned long long before_sh[4];
+    __shared__ uint32_t over_sh[4];
+    __shared__ uint32_t ns_sh[K1T_MAX_SPB], want_sh[K1T_MAX_SPB], first_sh[K1T_MAX_SPB], room_at[K1T_MAX_SPB], fits_sh[K1T_MAX_SPB], room_used;
+    /* a run: where its copies stand in dup_idx and its first table position; its place in the list
+     * is in rbase, its length the distance to the next one's place */
+    __shared__ uint2 run[K1T_MAX_SPB][K1T_LIST_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t rbase[K1T_MAX_SPB][K1T_LIST_CAP + 4u]; /* [16] = the list's length */
+    __shared__ uint4 all4[K1_EMIT_ROOM / 4u];
+    uint32_t *all = (uint32_t *)all4;
+    const uint32_t tid = threadIdx.x, l = tid % K1_WIDE_LANES;
+    const uint32_t tile = blockIdx.x, ntiles = gridDim.x, t0 = tile * spb;
+    const uint32_t nstr = min(spb, N - t0);
+    const bool last = tile + 1u == ntiles;
+    if (tid < 4u) {
+        before_sh[tid] = 0ull;
+        over_sh[tid] = 0u;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (mine && l == 0u) {
-        uint32_t at = 0;
-        for (uint32_t k = 0; k < ns; ++k) {
-            rbase[g][k] = at;
-            at += rlen[g][k];
+    __syncthreads();
+    /* step 1: everything that does not wait for anything else */
+    uint2 text[K1_EMIT_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_ROUNDS; ++k) {
+        const uint32_t g = min(tid / K1_WIDE_LANES + GPR * k, nstr - 1u);
+        /* past a string's last text the short list holds whatever the memory held, and the groups
+         * of lanes past the tile's last string read that one's: neither is looked at */
+        text[k] = make_uint2(0u, 0u);
+        if (idx != nullptr && GPR * k < nstr)
+            text[k] = texts[(size_t)(t0 + g) * K1T_LIST_CAP + l];
+    }
+    if (tid < K1T_MAX_SPB) {
+        const bool has = tid < nstr;
+        const uint32_t mine = t0 + min(tid, nstr - 1u);
+        const uint32_t cnt = count[mine], ns = nslots[mine];
+        ns_sh[tid] = has ? ns : 0u;
+        want_sh[tid] = !has ? 0u : K != 0u && cnt > K ? K : cnt;
+    }
+    unsigned long long before = 0;
+    uint32_t over = 0;
+    if (tile_off == nullptr) {
+        for (uint32_t t = tid; t < tile; t += K1_EMIT_THREADS)
+            before += tile_sum[t];
+        if (last)
+            for (uint32_t t = tid; t < ntiles; t += K1_EMIT_THREADS)
+                over += tile_over[t];
+        if (before != 0ull)
+            atomicAdd(&before_sh[tid & 3u], before);
+        if (over != 0u)
+            atomicAdd(&over_sh[tid & 3u], over);
+    } else if (tid == 0u) {
+        before_sh[0] = tile_off[tile];
+        over_sh[0] = last ? (uint32_t)tile_off[ntiles + 1u] : 0u;
+    }
+    __syncthreads();
+    /* step 2: the runs of every list (where their copies stand: asked for in one go), and the lists' places */
+    uint32_t at_dup[K1_EMIT_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_ROUNDS; ++k) {
+        const uint32_t g = tid / K1_WIDE_LANES + GPR * k;
+        at_dup[k] = 0u;
+        if (GPR * k >= nstr)
+            continue; /* the whole round is past the tile's last string */
+        const uint32_t ns = ns_sh[g];
+        const bool listed = idx != nullptr && ns <= K1T_LIST_CAP && l < ns && want_sh[g] != 0u;
+        if (!listed)
+            text[k].y = 0u; /* 0 in the lanes past the last text */
+        if (text[k].y > 1u)
+            at_dup[k] = dup_start[text[k].x];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_ROUNDS; ++k) {
+        const uint32_t g = tid / K1_WIDE_LANES + GPR * k;
+        if (GPR * k >= nstr)
+            continue;
+        const uint32_t mult = text[k].y;
+        /* running sums over the sixteen lanes of a list: a row of the data-parallel primitives, whose
+         * lanes without a lane that far to their left read 0 */
+        uint32_t incl = mult;
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);
+        run[g][l] = make_uint2(at_dup[k], text[k].x);
+        rbase[g][l] = incl - mult;
+        if (l == K1_WIDE_LANES - 1u)
+            rbase[g][K1_WIDE_LANES] = incl;
+    }
+    if (tid < 64u) {
+        /* one wave: the strings' places in the caller's array, and in the block's room in LDS */
+        const uint32_t w = over_sh[0] + over_sh[1] + over_sh[2] + over_sh[3];
+        const unsigned long long tiles_before = before_sh[0] + before_sh[1] + before_sh[2] + before_sh[3];
+        const uint32_t want = tid < K1T_MAX_SPB ? want_sh[tid] : 0u;
+        uint32_t incl = want;
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (tid >= d)
+                incl += o;
         }
-        rbase[g][ns] = at;
+        const unsigned long long place = tiles_before + (incl - want);
+        if (tid < nstr)
+            off[t0 + tid] = (uint32_t)place;
+        if (tid < K1T_MAX_SPB)
+            first_sh[tid] = incl - want;
+        if (last && tid == 63u) {
+            const unsigned long long total = tiles_before + incl;
+            off[N] = (uint32_t)total;
+            /* Two words for the host, each stored as a whole and each marked with the call's number
+             * in its upper bits: the host waits for both marks, not for the end of the kernel, and no
+             * fence (which would write back the whole L2) has to order anything. */
+            const unsigned long long mark = (unsigned long long)seq << K1_REPORT_BITS;
+            const unsigned long long most = (1ull << K1_REPORT_BITS) - 1ull;
+            __hip_atomic_store(h_totals, mark | (total < most ? total : most), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(h_totals + 1, mark | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t total = mine ? rbase[g][ns] : 0u;
-    uint32_t *dst = idx + (mine ? off[i] : 0u);
-    /* a list of up to K1_WIDE_ALL entries (nearly all of them): its entries are gathered into LDS once
-     * and every one is ranked against all the others there - a place in the list is the number of
-     * smaller entries - instead of by bisection through the other runs in global memory, a chain
-     * of dependent loads per entry */
-    const bool small = mine && total <= K1_WIDE_ALL;
-    if (small) {
+    if (idx == nullptr)
+        return; /* the places only */
+    __syncthreads();
+    if (tid < 64u) {
+        /* Room in LDS for the entries of the lists of up to K1_EMIT_PAIRS entries, all of them (a
+         * list cut at K is gathered whole), each list's room a whole number of 16-byte words.
+         * The first list that finds no room ends the part of the room that is used: those
+         * behind it would find none either. */
+        const uint32_t len = tid < ((nstr + GPR - 1u) & ~(GPR - 1u)) ? rbase[tid][K1_WIDE_LANES] : 0u;
+        const uint32_t whole = len <= K1_EMIT_PAIRS ? (len + 3u) & ~3u : K1_EMIT_ROOM + 4u;
+        uint32_t incl = whole;
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (tid >= d)
+                incl += o;
+        }
+        const bool fits = incl <= K1_EMIT_ROOM;
+        uint32_t used = fits ? incl : 0u; /* the largest end of a list that fits */
+        for (int d = 32; d > 0; d >>= 1)
+            used = max(used, (uint32_t)__shfl_xor(used, d));
+        if (tid < K1T_MAX_SPB) {
+            room_at[tid] = fits ? incl - whole : K1_EMIT_ROOM; /* past every place that is used */
+            fits_sh[tid] = fits ? 1u : 0u;
+        }
+        if (tid == 0u)
+            room_used = used;
+    }
+    __syncthreads();
+    /* step 3: the entries themselves, a thread per place of the room and round, all asked for in
+     * one go.  A place belongs to the last list that starts at or before it (lists without room
+     * start where the next one does); entry e of a list belongs to the last run that starts at or
+     * before e: the starts ascend, and those of the runs a list does not have equal its length. */
+    const uint32_t used = room_used;
+    uint32_t lead[K1_EMIT_SLOTS], owner[K1_EMIT_SLOTS];
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k) {
+        const uint32_t s = tid + K1_EMIT_THREADS * k;
+        lead[k] = 0xFFFFFFFFu; /* past a list's end: above every table position */
+        owner[k] = 0xFFFFFFFFu;
+        if (s < used) {
+            uint32_t g = 0;
+#pragma unroll
+            for (uint32_t step = K1T_MAX_SPB / 2u; step > 0u; step >>= 1)
+                if (room_at[g + step] <= s)
+                    g += step;
+            const uint32_t e = s - room_at[g];
+            if (e < rbase[g][K1_WIDE_LANES]) {
+                const uint4 *row = (const uint4 *)rbase[g];
+                const uint4 b0 = row[0], b1 = row[1];
+                uint32_t r = (b0.y <= e) + (b0.z <= e) + (b0.w <= e) + (b1.x <= e) + (b1.y <= e) + (b1.z <= e) +
+                             (b1.w <= e);
+                if (r == 7u) { /* few lists have more than eight runs */
+                    const uint4 b2 = row[2], b3 = row[3];
+                    r += (b2.x <= e) + (b2.y <= e) + (b2.z <= e) + (b2.w <= e) + (b3.x <= e) + (b3.y <= e) +
+                         (b3.z <= e) + (b3.w <= e);
+                }
+                const uint2 mine = run[g][r];
+                const uint32_t base = rbase[g][r];
+                owner[k] = g;
+                lead[k] = mine.y;
+                if (rbase[g][r + 1u] - base > 1u)
+                    lead[k] = dup_idx[mine.x + (e - base)];
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k)
+        if (tid + K1_EMIT_THREADS * k < used)
+            all[tid + K1_EMIT_THREADS * k] = lead[k];
+    __syncthreads();
+    /* step 4: every entry's place in its list */
+    const unsigned long long tiles_before = before_sh[0] + before_sh[1] + before_sh[2] + before_sh[3];
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k) {
+        const uint32_t g = owner[k];
+        if (g == 0xFFFFFFFFu)
+            continue;
+        const uint32_t total = rbase[g][K1_WIDE_LANES], at = room_at[g], want = want_sh[g];
+        const unsigned long long place = tiles_before + first_sh[g];
+        const unsigned long long room = place < cap ? cap - place : 0ull; /* entries of this list that fit */
+        uint32_t rank = 0;
+#pragma unroll 1
+        for (uint32_t o = at / 4u; o < (at + total + 3u) / 4u; ++o) {
+            const uint4 x = all4[o];
+            rank += (x.x < lead[k]) + (x.y < lead[k]) + (x.z < lead[k]) + (x.w < lead[k]);
+        }
+        if (rank < want && rank < room)
+            idx[place + rank] = lead[k]; /* table positions are distinct: so are the places */
+    }
+    /* the lists without room: sixteen lanes per list, every entry's place by bisection through the
+     * other runs in global memory */
+#pragma unroll 1
+    for (uint32_t k = 0; k < K1_EMIT_ROUNDS; ++k) {
+        const uint32_t g = tid / K1_WIDE_LANES + GPR * k;
+        if (GPR * k >= nstr)
+            break;
+        const uint32_t total = rbase[g][K1_WIDE_LANES], want = want_sh[g];
+        if (total == 0u || fits_sh[g] != 0u)
+            continue;
+        const unsigned long long place = tiles_before + first_sh[g];
+        uint32_t *dst = idx + (size_t)place;
+        const unsigned long long room = place < cap ? cap - place : 0ull;
+        const uint32_t ns = ns_sh[g];
         for (uint32_t e = l; e < total; e += K1_WIDE_LANES) {
             uint32_t r = 0;
             while (rbase[g][r + 1u] <= e)
                 ++r;
-            all[g][e] = rlen[g][r] > 1u ? dup_idx[rat[g][r] + (e - rbase[g][r])] : rhead[g][r];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (small) {
-        for (uint32_t e = l; e < total; e += K1_WIDE_LANES) {
-            const uint32_t v = all[g][e];
-            uint32_t rank = 0;
-            for (uint32_t o = 0; o < total; ++o)
-                rank += all[g][o] < v ? 1u : 0u; /* table positions are distinct */
-            if (rank < want)
+            const uint32_t p = e - rbase[g][r];
+            const uint32_t v = rbase[g][r + 1u] - rbase[g][r] > 1u ? dup_idx[run[g][r].x + p] : run[g][r].y;
+            uint32_t rank = p;
+            for (uint32_t o = 0; o < ns; ++o) {
+                if (o == r)
+                    continue;
+                const uint32_t len = rbase[g][o + 1u] - rbase[g][o];
+                if (len == 1u) {
+                    rank += run[g][o].y < v ? 1u : 0u;
+                } else {
+                    const uint32_t *q = dup_idx + run[g][o].x;
+                    uint32_t lo = 0, hi = len; /* entries of run o below v */
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (q[mid] < v)
+                            lo = mid + 1u;
+                        else
+                            hi = mid;
+                    }
+                    rank += lo;
+                }
+            }
+            if (rank < want && rank < room)
                 dst[rank] = v;
         }
-        return;
-    }
-    if (!mine)
-        return;
-    for (uint32_t e = l; e < total; e += K1_WIDE_LANES) {
-        uint32_t r = 0;
-        while (rbase[g][r + 1u] <= e)
-            ++r;
-        const uint32_t p = e - rbase[g][r];
-        const uint32_t v = rlen[g][r] > 1u ? dup_idx[rat[g][r] + p] : rhead[g][r];
-        uint32_t rank = p;
-        for (uint32_t o = 0; o < ns; ++o) {
-            if (o == r)
-                continue;
-            if (rlen[g][o] == 1u) {
-                rank += rhead[g][o] < v ? 1u : 0u;
-            } else {
-                const uint32_t *q = dup_idx + rat[g][o];
-                uint32_t lo = 0, hi = rlen[g][o]; /* entries of run o below v */
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (q[mid] < v)
-                        lo = mid + 1u;
-                    else
-                        hi = mid;
-                }
-                rank += lo;
-            }
-        }
-        if (rank < want)
-            dst[rank] = v;
     }
 }
 
-/* capped[i] = min(count[i], K) (K = 0: no limit, nothing written), and the number of strings
- * whose short list overflowed */
-__global__ void __launch_bounds__(256)
-k1_list_cap(const uint32_t *__restrict__ count, const uint32_t *__restrict__ nslots, uint32_t N, uint32_t K,
-            uint32_t *__restrict__ capped, uint32_t *__restrict__ overflow)
+/* Batches of more tiles than every block cares to add up by itself: tile_off[t] = entries of the
+ * tiles before t, tile_off[ntiles] = all of them, tile_off[ntiles + 1] = overflowed short lists.
+ * One block walks the tiles, 1024 at a step. */
+__global__ void __launch_bounds__(1024)
+k1_tile_offsets(const unsigned long long *__restrict__ tile_sum, const uint32_t *__restrict__ tile_over,
+                uint32_t ntiles, unsigned long long *__restrict__ tile_off)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool over = false;
-    if (i < N) {
-        if (K)
-            capped[i] = count[i] < K ? count[i] : K;
-        over = nslots[i] > K1T_LIST_CAP;
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wover[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned long long carry = 0;
+    uint32_t over = 0;
+    for (uint32_t c = 0; c < ntiles; c += 1024u) {
+        const uint32_t t = c + tid;
+        const unsigned long long v = t < ntiles ? tile_sum[t] : 0ull;
+        uint32_t ov = t < ntiles ? tile_over[t] : 0u;
+        unsigned long long incl = v;
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const unsigned long long o = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += o;
+        }
+        for (int d = 32; d > 0; d >>= 1)
+            ov += __shfl_xor(ov, d);
+        if (lane == 63u)
+            wsum[wave] = incl;
+        if (lane == 0u)
+            wover[wave] = ov;
+        __syncthreads();
+        unsigned long long below = 0, whole = 0;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            below += w < wave ? wsum[w] : 0ull;
+            whole += wsum[w];
+            over += wover[w];
+        }
+        if (t < ntiles)
+            tile_off[t] = carry + below + incl - v;
+        carry += whole;
+        __syncthreads();
     }
-    const unsigned long long m = __ballot(over);
-    if (m && (threadIdx.x & 63u) == 0u)
-        atomicAdd(overflow, (uint32_t)__popcll(m));
+    if (tid == 0u) {
+        tile_off[ntiles] = carry;
+        tile_off[ntiles + 1u] = over;
+    }
 }
 
 /* two 64-bit totals from device memory into pinned host memory (one small launch is quicker
@@ -1974,6 +2167,33 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
     return MCX_OK;
 }
 
+/* Wait for the two marked words k1_list_place_emit leaves in pinned host memory (spinning on them
+ * costs a few microseconds, a stream synchronisation about 25); after 200 us without them,
+ * synchronise the stream instead, which also reports a failed launch. */
+static int k1_wait_report(mcx_ctx *ctx, uint32_t seq, unsigned long long *total, uint32_t *overflows)
+{
+    volatile unsigned long long *h = (volatile unsigned long long *)ctx->h_pinned;
+    const unsigned long long most = (1ull << K1_REPORT_BITS) - 1ull;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (uint32_t spins = 0;; ++spins) {
+        const unsigned long long a = h[0], b = h[1];
+        if ((a >> K1_REPORT_BITS) == seq && (b >> K1_REPORT_BITS) == seq) {
+            *total = a & most;
+            *overflows = (uint32_t)(b & most);
+            return MCX_OK;
+        }
+        if (synced) {
+            ctx->err = "the match lists' report did not arrive";
+            return MCX_E_HIP;
+        }
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            synced = true;
+        }
+    }
+}
+
 /* the tile kernel in one of its list modes over the whole batch */
 static int launch_tiles_list(mcx_ctx *ctx, int mode, const uint8_t *d_S, const uint32_t *d_s_off, uint32_t N,
                              uint32_t *d_first, uint32_t *d_count, const k1_list_t &L)
@@ -2008,50 +2228,56 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
         return MCX_OK;
     }
     const uint32_t nb = (N + SCAN_ITEMS - 1u) / SCAN_ITEMS, grid = (N + 255u) / 256u;
-    /* scratch: first, count, number of matching texts, capped counts, offsets of the full lists
-     * (fallback), block sums, totals, and the short lists */
+    const uint32_t spb = k1t_strings_per_block(N), ntiles = (N + spb - 1u) / spb;
+    /* scratch: first, count, number of matching texts, offsets of the full lists (fallback),
+     * block sums and total of its scan, the tiles' sums, overflows and offsets, and the short lists */
     const size_t words = up256(4 * ((size_t)N + 1));
-    const size_t o_count = words, o_ns = 2 * words, o_cap = 3 * words, o_full = 4 * words, o_bsum = 5 * words;
-    const size_t o_total = o_bsum + up256(4 * (size_t)nb), o_slots = o_total + 256;
+    const size_t o_count = words, o_ns = 2 * words, o_full = 3 * words, o_bsum = 4 * words;
+    const size_t o_total = o_bsum + up256(4 * (size_t)nb), o_tsum = o_total + 256;
+    const size_t o_tover = o_tsum + up256(8 * (size_t)ntiles), o_toff = o_tover + up256(4 * (size_t)ntiles);
+    const size_t o_texts = o_toff + up256(8 * ((size_t)ntiles + 2));
     void *base;
-    int rc = mcx_scratch(ctx, o_slots + up256(4 * (size_t)N * K1T_LIST_CAP), &base);
+    int rc = mcx_scratch(ctx, o_texts + up256(8 * (size_t)N * K1T_LIST_CAP), &base);
     if (rc != MCX_OK)
         return rc;
     uint32_t *d_first = (uint32_t *)base, *d_count = (uint32_t *)((char *)base + o_count);
-    uint32_t *d_ns = (uint32_t *)((char *)base + o_ns), *d_capped = (uint32_t *)((char *)base + o_cap);
+    uint32_t *d_ns = (uint32_t *)((char *)base + o_ns);
     uint32_t *d_full = (uint32_t *)((char *)base + o_full), *d_bsum = (uint32_t *)((char *)base + o_bsum);
-    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total); /* [0] kept, [1] overflows */
-    uint32_t *d_over = (uint32_t *)(d_total + 1);
-    uint32_t *d_slots = (uint32_t *)((char *)base + o_slots);
+    unsigned long long *d_total = (unsigned long long *)((char *)base + o_total);
+    unsigned long long *d_tsum = (unsigned long long *)((char *)base + o_tsum);
+    uint32_t *d_tover = (uint32_t *)((char *)base + o_tover);
+    unsigned long long *d_toff = (unsigned long long *)((char *)base + o_toff);
+    uint2 *d_texts = (uint2 *)((char *)base + o_texts);
     unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
-    k1_list_t L{nullptr, nullptr, ctx->d_dup_start, ctx->d_dup_idx, d_ns, d_slots};
-    /* one pass: counts, first matches and the short lists; then the places of the lists */
-    HIPCHK(ctx, hipMemsetAsync(d_total, 0, 16, ctx->stream));
+    k1_list_t L{nullptr, nullptr, ctx->d_dup_start, ctx->d_dup_idx, d_ns, d_texts, d_tsum, d_tover, K};
+    /* one pass: counts, first matches, the short lists and what every tile's lists hold together;
+     * then one launch that places the lists and writes them.  It does so before the host has seen
+     * the total (and keeps inside the caller's array by itself): the device does not sit idle
+     * through the host's round trip. */
     if ((rc = launch_tiles_list(ctx, 1, (const uint8_t *)d_S, (const uint32_t *)d_s_off, N, d_first, d_count, L)) !=
         MCX_OK)
         return rc;
-    k1_list_cap<<<grid, 256, 0, ctx->stream>>>(d_count, d_ns, N, K, d_capped, d_over);
-    mcx_scan_enqueue(ctx->stream, K ? d_capped : d_count, N, d_bsum, d_total, (uint32_t *)d_list_off);
     unsigned long long *dh_total = nullptr; /* the pinned words as the device addresses them */
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&dh_total, h_total, 0));
-    k1_publish2<<<1, 64, 0, ctx->stream>>>(d_total, dh_total);
-    /* the lists themselves are enqueued before the host looks at the totals (the kernels look
-     * for themselves and write nothing when the lists do not fit or a short list overflowed):
-     * the device does not sit idle through the host's round trip */
+    const bool direct = ntiles <= K1_TILES_DIRECT;
+    /* the report's words start out unmarked (they serve other calls' read-backs too); the mark is never 0 */
+    const uint32_t seq = (mcx_next_seq(ctx) & 0xFFFFFFu) | 0x800000u;
+    h_total[0] = 0ull;
+    h_total[1] = 0ull;
+    if (!direct)
+        k1_tile_offsets<<<1, 1024, 0, ctx->stream>>>(d_tsum, d_tover, ntiles, d_toff);
     const bool emitted = !ctx->list_two_pass && d_list_idx != nullptr;
-    if (emitted) {
-        k1_list_emit<<<grid, 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start, ctx->d_dup_idx,
-                                                    (const uint32_t *)d_list_off, N, (uint32_t *)d_list_idx, d_total,
-                                                    (unsigned long long)cap);
-        k1_list_emit_wide<<<(N + 256u / K1_WIDE_LANES - 1u) / (256u / K1_WIDE_LANES), 256, 0, ctx->stream>>>(d_ns, d_slots, ctx->d_slot, ctx->d_dup_start,
-                                                                 ctx->d_dup_idx, (const uint32_t *)d_list_off, N,
-                                                                 (uint32_t *)d_list_idx, d_total,
-                                                                 (unsigned long long)cap);
-    }
+    k1_list_place_emit<<<ntiles, K1_EMIT_THREADS, 0, ctx->stream>>>(
+        d_count, d_ns, d_texts, ctx->d_dup_start, ctx->d_dup_idx, N, spb, K, d_tsum, d_tover,
+        direct ? nullptr : d_toff, (uint32_t *)d_list_off, emitted ? (uint32_t *)d_list_idx : nullptr,
+        (unsigned long long)cap, dh_total, seq);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long kept = h_total[0];
-    const uint32_t overflows = (uint32_t)h_total[1];
+    /* the totals are out as soon as the last tile's lists have their places: the lists themselves
+     * follow in stream order, like the results of every other *_dev call */
+    unsigned long long kept = 0;
+    uint32_t overflows = 0;
+    if ((rc = k1_wait_report(ctx, seq, &kept, &overflows)) != MCX_OK)
+        return rc;
     *total_out = kept;
     if (kept > 0xFFFFFFFFull) {
         ctx->err = "more than 2^32 - 1 matches: split the batch";

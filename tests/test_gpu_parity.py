@@ -96,7 +96,8 @@ def test_k1_match_lists(gpu_ctx, oracle_mod):
     off, idx = gpu_ctx.alias_match_list(S, s_off)
     for i, q in enumerate(fx["queries"]):
         assert [mods[j] for j in idx[off[i]:off[i + 1]]] == q["modules"], q
-    for seed, P, N, K in ((12, 3000, 700, 0), (13, 3000, 700, 2), (14, 500, 70000, 0), (15, 500, 70000, 3)):
+    for seed, P, N, K in ((12, 3000, 700, 0), (13, 3000, 700, 2), (14, 500, 70000, 0), (15, 500, 70000, 3),
+                           (16, 500, 200000, 0), (17, 500, 200000, 2)):
         A, a_off, a_mod = synth.alias_table(seed, P)
         # repeat a tenth of the table at the end: same texts at later positions
         pats = [A[a_off[j]:a_off[j + 1]].tobytes() for j in range(P)]
