@@ -5,6 +5,7 @@ synthetic modalias strings already resident in HBM - configs[1] of the benchmark
 1000 strings x 30000 alias patterns, seed 2.  Beside the headline value the line carries
   roofline      algorithmic bytes of one K1 launch / measured device time
   cpu_baseline  the CPU oracle (glibc fnmatch loop) timed on the host cores
+  lists         match lists against first / count alone, 70000 strings on the same table
   k2            dependency flags + closure on configs[2] (1M modules, ~10M edges)
   fleet         the fused inventory pipeline on configs[4] (100000 hosts, ~10M devices)
   configs3      1M strings x 3M patterns on this one GPU
@@ -296,6 +297,7 @@ def bench_one_gpu(ctx, synth, args, torch, stream, fence, local_rank):
         out["cpu_baseline"] = cpu_baseline_k1(A, a_off, S, s_off, args.cpu_seconds)
     for b in (d_S, d_off):
         b.free()
+    out["lists"] = bench_lists(ctx, synth, args, with_cpu=not args.no_cpu)
     if not args.no_k2:
         out["k2"] = bench_k2(ctx, synth, args, with_cpu=not args.no_cpu)
     if not args.no_fleet:
@@ -303,6 +305,44 @@ def bench_one_gpu(ctx, synth, args, torch, stream, fence, local_rank):
     if not args.no_configs3:
         out["configs3"] = bench_configs3(ctx, synth, args, with_cpu=not args.no_cpu)
     return out
+
+
+def bench_lists(ctx, synth, args, with_cpu=False):
+    """Match lists (every matching table position per string, kmod's order) against first / count
+    alone, 70 000 strings on the table that is loaded (configs[1]'s)."""
+    N, P = 70000, args.patterns
+    S, s_off = synth.modalias_strings(args.seed, P, N)
+    d_S, d_off = ctx.to_device(S), ctx.to_device(s_off)
+    d_f, d_c, d_l = ctx.alloc(4 * N), ctx.alloc(4 * N), ctx.alloc(4 * (N + 1))
+    total = ctx.alias_match_list_dev(d_S.ptr, d_off.ptr, N, 0, d_l.ptr, None, 0, size_only=True)
+    d_i = ctx.alloc(4 * max(total, 1))
+    res = {"workload": f"{N} modalias strings x {P} alias patterns, seed {args.seed}, resident in HBM",
+           "entries": int(total)}
+    for name, fn in (("first_count_us", lambda: ctx.alias_match_dev(d_S.ptr, d_off.ptr, N, d_f.ptr, d_c.ptr)),
+                     ("lists_us", lambda: ctx.alias_match_list_dev(d_S.ptr, d_off.ptr, N, 0, d_l.ptr, d_i.ptr, total)),
+                     ("lists_first3_us",
+                      lambda: ctx.alias_match_list_dev(d_S.ptr, d_off.ptr, N, 3, d_l.ptr, d_i.ptr, total))):
+        for _ in range(3):
+            fn()
+        ctx.sync()
+        ctx.timer_begin()
+        for _ in range(20):
+            fn()
+        res[name] = ctx.timer_end() / 20 * 1e3
+    res["lists_over_first_count"] = res["lists_us"] / res["first_count_us"]
+    if with_cpu:
+        import oracle
+
+        ctx.alias_match_list_dev(d_S.ptr, d_off.ptr, N, 0, d_l.ptr, d_i.ptr, total)
+        off, idx = d_l.download(np.uint32, N + 1), d_i.download(np.uint32, total)
+        n_chk = 64
+        A, a_off, _ = synth.alias_table(args.seed, P)
+        o_off, o_idx = oracle.alias_match_list(A, a_off, S[: s_off[n_chk]], s_off[: n_chk + 1])
+        if not (np.array_equal(off[: n_chk + 1], o_off) and np.array_equal(idx[: o_off[n_chk]], o_idx)):
+            raise SystemExit("bench: match lists differ from the oracle")
+    for b in (d_S, d_off, d_f, d_c, d_l, d_i):
+        b.free()
+    return res
 
 
 def configs3_inputs(synth, args, j0=0, j1=None):
