@@ -182,6 +182,38 @@ def test_k1_match_lists_long_and_both_ways(gpu_ctx, oracle_mod, monkeypatch):
     assert np.array_equal(got[0][0][:301], o_off) and np.array_equal(got[0][1][: o_off[300]], o_idx)
 
 
+def test_k1_match_lists_of_many_copies(gpu_ctx, oracle_mod):
+    """Pattern texts that stand in the table dozens of times: lists of a few runs with up to 170
+    entries (past what the merge gathers in LDS per list), and tiles whose lists together outgrow
+    the room there.  Whole batch: list lengths = counts, first entries = first matches, every list
+    strictly ascending; 400 strings entry by entry against the oracle; with and without a limit."""
+    rng = np.random.default_rng(11)
+    pats = [b"q:*"] * 30 + [b"q:a*"] * 20 + [b"q:?b*"] * 12 + [b"r:*"] * 100 + [b"r:x*"] * 70
+    pats += [b"q:ab%d" % d for d in range(10)] + [b"r:x%d*" % d for d in range(10)] + [b"s:%d" % d for d in range(50)]
+    pats = [pats[i] for i in rng.permutation(len(pats))]
+    A, a_off = pack_strings(pats)
+    kinds = [b"q:ab%d", b"q:a%d", b"q:zb%d", b"q:%d", b"r:x%d", b"r:y%d", b"s:%d", b"t:%d"]
+    N = 40000
+    strs = [kinds[k] % d for k, d in zip(rng.integers(0, len(kinds), N), rng.integers(0, 12, N))]
+    S, s_off = pack_strings(strs)
+    gpu_ctx.alias_table_load(A, a_off, np.zeros(len(pats), dtype=np.uint32))
+    first, count = gpu_ctx.alias_match(S, s_off)
+    assert count.max() >= 170
+    sample = np.unique(np.concatenate([np.arange(0, N, 100), np.argsort(-count.astype(np.int64))[:5]]))
+    Ss, ss_off = pack_strings([strs[i] for i in sample])
+    for K in (0, 40):
+        off, idx = gpu_ctx.alias_match_list(S, s_off, K=K)
+        want_n = np.minimum(count, K) if K else count
+        assert np.array_equal(np.diff(off.astype(np.int64)), want_n)
+        assert np.array_equal(idx[off[:-1][want_n > 0]], first[want_n > 0])
+        inner = np.ones(len(idx), dtype=bool)
+        inner[off[:-1][want_n > 0]] = False           # not the first entry of a list
+        assert (idx[1:][inner[1:]] > idx[:-1][inner[1:]]).all()
+        o_off, o_idx = oracle_mod.alias_match_list(A, a_off, Ss, ss_off, K=K)
+        for n, i in enumerate(sample):
+            assert np.array_equal(idx[off[i]:off[i + 1]], o_idx[o_off[n]:o_off[n + 1]]), i
+
+
 @pytest.mark.parametrize("seed,P,N", [(2, 30000, 1000), (5, 777, 130), (6, 63, 1), (7, 5, 65), (8, 4096, 64)])
 def test_k1_synthetic_vs_oracle(gpu_ctx, oracle_mod, seed, P, N):
     """configs[1] (1000 x 30000, seed 2) and ragged shapes around the tile sizes"""
