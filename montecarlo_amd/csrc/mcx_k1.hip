@@ -1592,14 +1592,18 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
 #pragma unroll
     for (uint32_t k = 0; k < K1_EMIT_ROUNDS; ++k) {
         const uint32_t g = tid / K1_WIDE_LANES + GPR * k;
-        at_dup[k] = 0u;
         if (GPR * k >= nstr)
             continue; /* the whole round is past the tile's last string */
         const uint32_t ns = ns_sh[g];
         const bool listed = idx != nullptr && ns <= K1T_LIST_CAP && l < ns && want_sh[g] != 0u;
         if (!listed)
             text[k].y = 0u; /* 0 in the lanes past the last text */
-        if (text[k].y > 1u)
+    }
+    /* (a loop of its own: the four requests leave together, none waits for the one before) */
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_ROUNDS; ++k) {
+        at_dup[k] = 0u;
+        if (GPR * k < nstr && text[k].y > 1u)
             at_dup[k] = dup_start[text[k].x];
     }
 #pragma unroll
@@ -1682,12 +1686,13 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
      * start where the next one does); entry e of a list belongs to the last run that starts at or
      * before e: the starts ascend, and those of the runs a list does not have equal its length. */
     const uint32_t used = room_used;
-    uint32_t lead[K1_EMIT_SLOTS], owner[K1_EMIT_SLOTS];
+    uint32_t lead[K1_EMIT_SLOTS], owner[K1_EMIT_SLOTS], copy_at[K1_EMIT_SLOTS];
 #pragma unroll
     for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k) {
         const uint32_t s = tid + K1_EMIT_THREADS * k;
         lead[k] = 0xFFFFFFFFu; /* past a list's end: above every table position */
         owner[k] = 0xFFFFFFFFu;
+        copy_at[k] = 0xFFFFFFFFu;
         if (s < used) {
             uint32_t g = 0;
 #pragma unroll
@@ -1710,10 +1715,15 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
                 owner[k] = g;
                 lead[k] = mine.y;
                 if (rbase[g][r + 1u] - base > 1u)
-                    lead[k] = dup_idx[mine.x + (e - base)];
+                    copy_at[k] = mine.x + (e - base);
             }
         }
     }
+    /* (a loop of its own: the requests leave together) */
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k)
+        if (copy_at[k] != 0xFFFFFFFFu)
+            lead[k] = dup_idx[copy_at[k]];
 #pragma unroll
     for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k)
         if (tid + K1_EMIT_THREADS * k < used)
@@ -1721,23 +1731,40 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
     __syncthreads();
     /* step 4: every entry's place in its list */
     const unsigned long long tiles_before = before_sh[0] + before_sh[1] + before_sh[2] + before_sh[3];
+    uint32_t rank[K1_EMIT_SLOTS];
 #pragma unroll
     for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k) {
         const uint32_t g = owner[k];
+        rank[k] = 0xFFFFFFFFu;
         if (g == 0xFFFFFFFFu)
             continue;
-        const uint32_t total = rbase[g][K1_WIDE_LANES], at = room_at[g], want = want_sh[g];
-        const unsigned long long place = tiles_before + first_sh[g];
-        const unsigned long long room = place < cap ? cap - place : 0ull; /* entries of this list that fit */
-        uint32_t rank = 0;
+        const uint32_t total = rbase[g][K1_WIDE_LANES], at = room_at[g];
+        uint32_t below = 0;
 #pragma unroll 1
         for (uint32_t o = at / 4u; o < (at + total + 3u) / 4u; ++o) {
             const uint4 x = all4[o];
-            rank += (x.x < lead[k]) + (x.y < lead[k]) + (x.z < lead[k]) + (x.w < lead[k]);
+            below += (x.x < lead[k]) + (x.y < lead[k]) + (x.z < lead[k]) + (x.w < lead[k]);
         }
-        if (rank < want && rank < room)
-            idx[place + rank] = lead[k]; /* table positions are distinct: so are the places */
+        rank[k] = below;
     }
+    /* (the stores in a loop of their own, behind all the counting and with their addresses ready: a
+     * register that a store still reads cannot be written, so anything in between would wait for it) */
+    uint32_t *to[K1_EMIT_SLOTS];
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k) {
+        const uint32_t g = owner[k];
+        to[k] = nullptr;
+        if (g == 0xFFFFFFFFu)
+            continue;
+        const unsigned long long place = tiles_before + first_sh[g];
+        const unsigned long long room = place < cap ? cap - place : 0ull; /* entries of this list that fit */
+        if (rank[k] < want_sh[g] && rank[k] < room)
+            to[k] = idx + (place + rank[k]); /* table positions are distinct: so are the places */
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < K1_EMIT_SLOTS; ++k)
+        if (to[k] != nullptr)
+            *to[k] = lead[k];
     /* the lists without room: sixteen lanes per list, every entry's place by bisection through the
      * other runs in global memory */
 #pragma unroll 1
