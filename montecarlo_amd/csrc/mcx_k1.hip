@@ -75,6 +75,33 @@ struct k1_list_t {
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
 
+/* The words of an index entry that a probe looks at: hash, key length, first pattern, count; the key.
+ * All 48 bytes are asked for at once and held to that: read field by field, the compiler asks
+ * for the count first and for each further field behind the look at the one before - a chain of
+ * round trips where the kernel's time is its chain of round trips. */
+struct k1_slot_words_t {
+    uint4 head, key_lo, key_hi;
+};
+
+__device__ __forceinline__ k1_slot_words_t k1_fetch_slot(const mcx_slot_t *p)
+{
+    static_assert(sizeof(mcx_slot_t) == 64 && MCX_KEY_MAX == 32, "entry layout as read here");
+    const uint4 *q = (const uint4 *)p;
+    k1_slot_words_t s{q[0], q[1], q[2]};
+    asm volatile("" : "+v"(s.head.x), "+v"(s.head.y), "+v"(s.head.z), "+v"(s.head.w), "+v"(s.key_lo.x),
+                 "+v"(s.key_lo.y), "+v"(s.key_lo.z), "+v"(s.key_lo.w), "+v"(s.key_hi.x), "+v"(s.key_hi.y),
+                 "+v"(s.key_hi.z), "+v"(s.key_hi.w));
+    return s;
+}
+
+/* the entry holds this key (an empty entry holds none: its length is 0) */
+__device__ __forceinline__ bool k1_slot_is(const k1_slot_words_t &s, uint32_t hash, uint32_t len, const uint32_t (&kw)[8])
+{
+    return ((s.head.x ^ hash) | (s.head.y ^ len) | (s.key_lo.x ^ kw[0]) | (s.key_lo.y ^ kw[1]) | (s.key_lo.z ^ kw[2]) |
+            (s.key_lo.w ^ kw[3]) | (s.key_hi.x ^ kw[4]) | (s.key_hi.y ^ kw[5]) | (s.key_hi.z ^ kw[6]) |
+            (s.key_hi.w ^ kw[7])) == 0u;
+}
+
 /* a string staged in LDS: `at` is its byte offset in the word array; the array
  * is padded, so reading a few bytes past the string's end is safe */
 struct LdsStr {
@@ -363,19 +390,15 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                 }
                 const uint32_t a = mcx_key_hash(kw, KL);
                 for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
-                    const mcx_slot_t sl = T.slots[at];
-                    if (sl.count == 0u)
-                        break;
-                    bool same = sl.hash == a && sl.len == KL;
-#pragma unroll
-                    for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
-                        same = same && sl.key[k] == kw[k];
+                    const k1_slot_words_t sl = k1_fetch_slot(T.slots + at);
+                    const bool same = k1_slot_is(sl, a, KL, kw);
                     if (same) {
-                        e_start = sl.start;
-                        e_cnt = sl.count;
+                        e_start = sl.head.z;
+                        e_cnt = sl.head.w;
                         e_slot = slot;
-                        break;
                     }
+                    if (sl.head.w == 0u || same)
+                        break;
                 }
             }
         }
@@ -509,17 +532,12 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
         for (uint32_t at = a & T.slot_mask;; at = (at + 1u) & T.slot_mask) {
             /* the 64-byte entry at once: the tag bytes the large-batch kernel asks first would
              * only lengthen this kernel's chain of dependent loads */
-            const mcx_slot_t sl = T.slots[at];
-            if (sl.count == 0u)
+            const k1_slot_words_t sl = k1_fetch_slot(T.slots + at);
+            const bool same = k1_slot_is(sl, a, L, kw);
+            if (same)
+                emit_hit(sl.head.z, sl.head.w, slot);
+            if (sl.head.w == 0u || same)
                 break;
-            bool same = sl.hash == a && sl.len == L;
-#pragma unroll
-            for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
-                same = same && sl.key[k] == kw[k];
-            if (same) {
-                emit_hit(sl.start, sl.count, slot);
-                break;
-            }
         }
     }
 #ifdef MCX_K1_STAMPS
