@@ -20,7 +20,7 @@ step() { # name, seconds, command...
 }
 step bench_stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- \
     python3 bench.py --steps 200 --warmup 20
-tail -n 1 "$OUT/bench_stats.log" > "$OUT/bench_line_under_profiler.json"
+grep "^{" "$OUT/bench_stats.log" | tail -n 1 > "$OUT/bench_line_under_profiler.json" # the bench line (the profiler prints after it)
 # HBM traffic of the bench's own kernels: the same command without its CPU legs and large cases
 step bench_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_fetch" -- \
     python3 bench.py --no-cpu --no-fleet --no-configs3 --repeats 3
