@@ -94,6 +94,15 @@ __device__ __forceinline__ k1_slot_words_t k1_fetch_slot(const mcx_slot_t *p)
     return s;
 }
 
+/* an entry of the second index (gram, group, first pattern, count) in one 16-byte load, for the same reason */
+__device__ __forceinline__ uint4 k1_fetch_sub(const mcx_sub_t *p)
+{
+    static_assert(sizeof(mcx_sub_t) == 16, "entry layout as read here");
+    uint4 e = *(const uint4 *)p;
+    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));
+    return e;
+}
+
 /* the entry holds this key (an empty entry holds none: its length is 0) */
 __device__ __forceinline__ bool k1_slot_is(const k1_slot_words_t &s, uint32_t hash, uint32_t len, const uint32_t (&kw)[8])
 {
@@ -1081,7 +1090,8 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
             const uint32_t *sp = T.slot + (size_t)kk * MCX_SLOT_WORDS;
             /* header, table position, multiplicity and the first directory word in one request:
              * a match then has what it reports without another round trip */
-            const uint4 head = *(const uint4 *)sp;
+            uint4 head = *(const uint4 *)sp;
+            asm volatile("" : "+v"(head.x), "+v"(head.y), "+v"(head.z), "+v"(head.w)); /* (held to one request) */
             static_assert(MCX_SLOT_MULT == 2u && MCX_SLOT_DIR == 3u, "slot words 0..3 as read here");
             const uint32_t hdr = head.x;
             const bool is_ext = (MCX_HDR_FLAGS(hdr) & MCX_PF_EXT) != 0u;
@@ -1225,6 +1235,22 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                     }
                 }
             }
+            /* nearly every walk ends inside the first word of tags, with at most one entry to look
+             * at: those entries - of all the turn's pairs - are asked for together; the other walks
+             * loop behind */
+            uint4 first_en[K1T_PAIRS];
+            uint32_t cands[K1T_PAIRS];
+#pragma unroll
+            for (uint32_t i = 0; i < K1T_PAIRS; ++i) {
+                first_en[i] = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u); /* no group has this number */
+                cands[i] = 0u;
+                if (act[i]) {
+                    const uint32_t tg = mcx_key_tag(h[i]) * 0x01010101u;
+                    cands[i] = k1_zero_bytes(tag[i] ^ tg) & k1_below_lowest(k1_zero_bytes(tag[i]));
+                    if (cands[i] != 0u)
+                        first_en[i] = *(const uint4 *)(T.sub + (((h[i] & T.sub_mask) + ((uint32_t)__builtin_ctz(cands[i]) >> 3)) & T.sub_mask));
+                }
+            }
 #pragma unroll
             for (uint32_t i = 0; i < K1T_PAIRS; ++i) {
                 const uint32_t b = b0 + K1T_PAIRS * wave + i;
@@ -1232,21 +1258,18 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                     break; /* the same for the whole wave */
                 bool found = false;
                 uint32_t fstart = 0, fcnt = 0;
-                /* nearly every walk ends inside the first word of tags, with at most one entry to
-                 * look at: that case runs straight through, the others loop behind it */
                 bool walk_on = false;
-                uint32_t t4 = tag[i], cand = 0, p = h[i] & T.sub_mask;
+                uint32_t t4 = tag[i], cand = cands[i], p = h[i] & T.sub_mask;
                 const uint32_t tg = mcx_key_tag(h[i]) * 0x01010101u, gid = key[i] >> 6;
                 if (act[i]) {
                     const uint32_t empty = k1_zero_bytes(t4);
-                    cand = k1_zero_bytes(t4 ^ tg) & k1_below_lowest(empty);
                     if (cand != 0u) {
-                        const mcx_sub_t en = T.sub[(p + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.sub_mask];
+                        const uint4 en = first_en[i];
                         cand &= cand - 1u;
-                        if (en.gram == w[i] && en.gid == gid) {
+                        if (((en.x ^ w[i]) | (en.y ^ gid)) == 0u) {
                             found = true;
-                            fstart = en.start;
-                            fcnt = en.count;
+                            fstart = en.z;
+                            fcnt = en.w;
                         }
                     }
                     walk_on = !found && (cand != 0u || empty == 0u);
@@ -1254,12 +1277,12 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                 if (__ballot(walk_on) != 0ull && walk_on) {
                     for (;;) {
                         while (cand != 0u && !found) {
-                            const mcx_sub_t en = T.sub[(p + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.sub_mask];
+                            const uint4 en = k1_fetch_sub(T.sub + ((p + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.sub_mask));
                             cand &= cand - 1u;
-                            if (en.gram == w[i] && en.gid == gid) {
+                            if (((en.x ^ w[i]) | (en.y ^ gid)) == 0u) {
                                 found = true;
-                                fstart = en.start;
-                                fcnt = en.count;
+                                fstart = en.z;
+                                fcnt = en.w;
                             }
                         }
                         if (found || k1_zero_bytes(t4) != 0u)
@@ -1384,21 +1407,20 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                     uint32_t cand = k1_zero_bytes(t4 ^ my_tag) & k1_below_lowest(empty);
                     done = empty != 0u;
                     while (cand != 0u) {
-                        const mcx_slot_t sl = T.slots[(at + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.slot_mask];
+                        const mcx_slot_t *sp = T.slots + ((at + ((uint32_t)__builtin_ctz(cand) >> 3)) & T.slot_mask);
+                        const k1_slot_words_t sl = k1_fetch_slot(sp);
+                        uint2 pad = *(const uint2 *)sp->pad; /* second index of the group, and what it leaves out */
+                        asm volatile("" : "+v"(pad.x), "+v"(pad.y));
                         cand &= cand - 1u;
-                        bool same = sl.hash == a && sl.len == KL;
-#pragma unroll
-                        for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
-                            same = same && sl.key[k] == kw[k];
-                        if (same) {
-                            if (sl.pad[0] != 0u && use_lds && len <= K1T_SUB_MAX_LEN) {
+                        if (k1_slot_is(sl, a, KL, kw)) {
+                            if (pad.x != 0u && use_lds && len <= K1T_SUB_MAX_LEN) {
                                 const uint32_t bi = atomicAdd(&nbig_sh, 1u);
-                                big_key[bi] = slot | ((sl.pad[0] - 1u) << 6);
-                                big_start[bi] = sl.start;
-                                big_count[bi] = sl.count;
-                                big_rest[bi] = sl.pad[1];
+                                big_key[bi] = slot | ((pad.x - 1u) << 6);
+                                big_start[bi] = sl.head.z;
+                                big_count[bi] = sl.head.w;
+                                big_rest[bi] = pad.y;
                             } else {
-                                push_run(sl.start, sl.count, slot);
+                                push_run(sl.head.z, sl.head.w, slot);
                             }
                             done = true;
                             break;
