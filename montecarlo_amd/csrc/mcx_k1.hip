@@ -1554,7 +1554,7 @@ k1_list_sort_long(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__rest
 #define K1_WIDE_LANES 16u
 #define K1_EMIT_THREADS 256u
 #define K1_EMIT_ROUNDS (K1T_MAX_SPB * K1_WIDE_LANES / K1_EMIT_THREADS)
-#define K1_EMIT_ROOM 1024u /* entries of a tile's lists that are gathered in LDS */
+#define K1_EMIT_ROOM 2048u /* entries of a tile's lists that are gathered in LDS */
 #define K1_EMIT_SLOTS (K1_EMIT_ROOM / K1_EMIT_THREADS)
 #define K1_EMIT_PAIRS 64u /* lists up to this length: gathered, every entry against every other */
 #define K1_REPORT_BITS 40u /* of a word of the report: the number; above them the call's mark */
