@@ -1557,6 +1557,7 @@ k1_list_sort_long(const uint32_t *__restrict__ off, uint32_t N, uint32_t *__rest
 #define K1_EMIT_ROOM 2048u /* entries of a tile's lists that are gathered in LDS */
 #define K1_EMIT_SLOTS (K1_EMIT_ROOM / K1_EMIT_THREADS)
 #define K1_EMIT_PAIRS 64u /* lists up to this length: gathered, every entry against every other */
+#define K1_NO_COPIES 0xFFFFFFFFu
 #define K1_REPORT_BITS 40u /* of a word of the report: the number; above them the call's mark */
 #define K1_TILES_DIRECT 2048u /* up to this many tiles every block adds up the tiles before it by itself */
 static_assert(K1_WIDE_LANES == K1T_LIST_CAP, "a lane per matching text");
@@ -1577,8 +1578,9 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
     __shared__ unsigned long long before_sh[4];
     __shared__ uint32_t over_sh[4];
     __shared__ uint32_t ns_sh[K1T_MAX_SPB], want_sh[K1T_MAX_SPB], first_sh[K1T_MAX_SPB], room_at[K1T_MAX_SPB], fits_sh[K1T_MAX_SPB], room_used;
-    /* a run: where its copies stand in dup_idx and its first table position; its place in the list
-     * is in rbase, its length the distance to the next one's place */
+    /* a run: where its copies stand in dup_idx (K1_NO_COPIES: a text that stands once in the table) and
+     * its table position (that of a text with copies: its slot number); its place in the list is in
+     * rbase, its length the distance to the next one's place */
     __shared__ uint2 run[K1T_MAX_SPB][K1T_LIST_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t rbase[K1T_MAX_SPB][K1T_LIST_CAP + 4u]; /* [16] = the list's length */
     __shared__ uint4 all4[K1_EMIT_ROOM / 4u];
@@ -1642,7 +1644,7 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
     /* (a loop of its own: the four requests leave together, none waits for the one before) */
 #pragma unroll
     for (uint32_t k = 0; k < K1_EMIT_ROUNDS; ++k) {
-        at_dup[k] = 0u;
+        at_dup[k] = K1_NO_COPIES;
         if (GPR * k < nstr && text[k].y > 1u)
             at_dup[k] = dup_start[text[k].x];
     }
@@ -1651,7 +1653,10 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
         const uint32_t g = tid / K1_WIDE_LANES + GPR * k;
         if (GPR * k >= nstr)
             continue;
-        const uint32_t mult = text[k].y;
+        /* Of a list cut at K, only the first K copies of a text can be among the first K entries, and
+         * an entry that is has all the smaller ones among those: the runs are cut at K too, and the
+         * places counted among what is left are the places in the whole list. */
+        const uint32_t mult = K != 0u && text[k].y > K ? K : text[k].y;
         /* running sums over the sixteen lanes of a list: a row of the data-parallel primitives, whose
          * lanes without a lane that far to their left read 0 */
         uint32_t incl = mult;
@@ -1754,7 +1759,7 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
                 const uint32_t base = rbase[g][r];
                 owner[k] = g;
                 lead[k] = mine.y;
-                if (rbase[g][r + 1u] - base > 1u)
+                if (mine.x != K1_NO_COPIES)
                     copy_at[k] = mine.x + (e - base);
             }
         }
@@ -1824,13 +1829,13 @@ k1_list_place_emit(const uint32_t *__restrict__ count, const uint32_t *__restric
             while (rbase[g][r + 1u] <= e)
                 ++r;
             const uint32_t p = e - rbase[g][r];
-            const uint32_t v = rbase[g][r + 1u] - rbase[g][r] > 1u ? dup_idx[run[g][r].x + p] : run[g][r].y;
+            const uint32_t v = run[g][r].x != K1_NO_COPIES ? dup_idx[run[g][r].x + p] : run[g][r].y;
             uint32_t rank = p;
             for (uint32_t o = 0; o < ns; ++o) {
                 if (o == r)
                     continue;
                 const uint32_t len = rbase[g][o + 1u] - rbase[g][o];
-                if (len == 1u) {
+                if (run[g][o].x == K1_NO_COPIES) {
                     rank += run[g][o].y < v ? 1u : 0u;
                 } else {
                     const uint32_t *q = dup_idx + run[g][o].x;
