@@ -950,32 +950,62 @@ static_assert(K1T_DEDUP_CELLS * K1T_WAVES <= K1T_RCAP, "the second index borrows
  * into L.idx at the place L.off (the exclusive sums of a counting pass) gives its string. */
 #define K1T_LIST_CAP 16u
 
+/* what a block of the tile kernel keeps in LDS */
 template <int MODE>
-__global__ void __launch_bounds__(K1T_THREADS, K1T_MIN_WAVES)
-k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
-               uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
-               uint32_t *__restrict__ count, const k1_list_t L)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t str_w[K1T_STR_BYTES / 4u + 8u];
-    __shared__ uint32_t bloom[K1T_MAX_SPB][MCX_BLOOM_WORDS];
-    __shared__ uint32_t str_at[K1T_MAX_SPB], str_len[K1T_MAX_SPB], refused[K1T_MAX_SPB];
-    __shared__ uint32_t res_first[K1T_MAX_SPB], res_count[K1T_MAX_SPB];
-    __shared__ uint32_t key_lens[MCX_KEY_MAX + 1];
-    constexpr bool LIST = MODE == 2;
-    __shared__ uint32_t lcount[MODE == 1 ? K1T_MAX_SPB : 1u]; /* matching pattern texts per string */
+struct k1t_shared_t {
+    __attribute__((aligned(16))) uint32_t str_w[K1T_STR_BYTES / 4u + 8u];
+    uint32_t bloom[K1T_MAX_SPB][MCX_BLOOM_WORDS];
+    uint32_t str_at[K1T_MAX_SPB], str_len[K1T_MAX_SPB], refused[K1T_MAX_SPB];
+    uint32_t res_first[K1T_MAX_SPB], res_count[K1T_MAX_SPB];
+    uint32_t key_lens[MCX_KEY_MAX + 1];
+    uint32_t lcount[MODE == 1 ? K1T_MAX_SPB : 1u]; /* matching pattern texts per string */
     /* candidate runs: first pattern, count (bits 0..25) | string slot (26..31); run_cum = exclusive sums */
-    __shared__ uint32_t run_start[K1T_RCAP], run_cnt[K1T_RCAP], run_cum[K1T_RCAP + 1u];
-    __shared__ uint32_t big_key[K1T_BCAP], big_start[K1T_BCAP], big_count[K1T_BCAP], big_rest[K1T_BCAP];
-    __shared__ uint32_t surv[K1T_SCAP];
-    __shared__ uint32_t nruns_sh, nbig_sh, nsurv_sh, wsum[K1T_WAVES];
+    uint32_t run_start[K1T_RCAP], run_cnt[K1T_RCAP], run_cum[K1T_RCAP + 1u];
+    uint32_t big_key[K1T_BCAP], big_start[K1T_BCAP], big_count[K1T_BCAP], big_rest[K1T_BCAP];
+    uint32_t surv[K1T_SCAP];
+    uint32_t nruns_sh, nbig_sh, nsurv_sh, wsum[K1T_WAVES];
+};
+
+/* The kernel's work on one tile.  INPLACE: the tile's strings do not fit the staging buffer and are
+ * read where they lie, byte by byte - rare, and compiled apart from the other case: with both in
+ * one body every step of the kernel carries the byte-wise path along, twice the code and twice the
+ * scalar registers. */
+template <int MODE, bool INPLACE>
+__device__ __forceinline__ void
+k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
+              uint32_t s_aligned, const k1_table_t &T, uint32_t *__restrict__ first_idx,
+              uint32_t *__restrict__ count, const k1_list_t &L, k1t_shared_t<MODE> &sh, uint32_t gbase, uint32_t gend)
+{
+    auto &str_w = sh.str_w;
+    auto &bloom = sh.bloom;
+    auto &str_at = sh.str_at;
+    auto &str_len = sh.str_len;
+    auto &refused = sh.refused;
+    auto &res_first = sh.res_first;
+    auto &res_count = sh.res_count;
+    auto &key_lens = sh.key_lens;
+    constexpr bool LIST = MODE == 2;
+    auto &lcount = sh.lcount;
+    auto &run_start = sh.run_start;
+    auto &run_cnt = sh.run_cnt;
+    auto &run_cum = sh.run_cum;
+    auto &big_key = sh.big_key;
+    auto &big_start = sh.big_start;
+    auto &big_count = sh.big_count;
+    auto &big_rest = sh.big_rest;
+    auto &surv = sh.surv;
+    auto &nruns_sh = sh.nruns_sh;
+    auto &nbig_sh = sh.nbig_sh;
+    auto &nsurv_sh = sh.nsurv_sh;
+    auto &wsum = sh.wsum;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t t0 = blockIdx.x * spb;
     const uint32_t nstr = min(spb, N - t0);
-    const uint32_t gbase = s_off[t0], gend = s_off[t0 + nstr], arena_end = s_off[N];
+    const uint32_t arena_end = s_off[N];
     const uint32_t total = gend - gbase;
-    const bool use_lds = total + 3u <= K1T_STR_BYTES;
+    constexpr bool use_lds = !INPLACE;
     const uint32_t shift = (use_lds && s_aligned) ? (gbase & 3u) : 0u;
 
     if (tid < T.nlens)
@@ -1465,6 +1495,22 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
             }
         }
     }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(K1T_THREADS, K1T_MIN_WAVES)
+k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off, uint32_t N, uint32_t spb,
+               uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
+               uint32_t *__restrict__ count, const k1_list_t L)
+{
+    __shared__ k1t_shared_t<MODE> sh;
+    const uint32_t t0 = blockIdx.x * spb;
+    const uint32_t gbase = s_off[t0], gend = s_off[t0 + min(spb, N - t0)];
+    /* the same for the whole block */
+    if (gend - gbase + 3u <= K1T_STR_BYTES)
+        k1_tiles_tile<MODE, false>(S, s_off, N, spb, s_aligned, T, first_idx, count, L, sh, gbase, gend);
+    else
+        k1_tiles_tile<MODE, true>(S, s_off, N, spb, s_aligned, T, first_idx, count, L, sh, gbase, gend);
 }
 
 /* Lists in ascending table order, in place.  Short lists: one thread each, insertion sort.
