@@ -11,7 +11,8 @@
  * meaning "could not tell"; list functions return a count and stop silently when
  * the caller's buffer is full; all buffers are caller allocated.
  *
- * The shipped library reads no environment variable.  (A separate test build,
+ * The shipped library reads no environment variable (it does not import getenv; what
+ * can be tuned is an argument of mcx_ctx_tune, mcx.h).  (A separate test build,
  * compiled with -DMCX_TEST_SEAMS and never installed, looks the absolute paths
  * the library builds itself - /sys/bus/..., /sys/module/..., /proc/modules - up
  * below $MCX_SYSFS_ROOT so that tests can walk a fake tree.)

@@ -83,6 +83,29 @@ const char *mcx_strerror(int rc);
  * pattern index ...); never NULL. */
 const char *mcx_last_error(mcx_ctx *ctx);
 
+/*
+ * Tuning knobs.  None of them changes a result; they choose between kernels and set the host
+ * threads of the table compiler, and they apply to tables loaded after the call.  The library
+ * reads no environment variable: a process that wants a knob turned calls this.
+ *   MCX_TUNE_COMPILE_THREADS  host threads mcx_alias_table_load may use (0 = one per core,
+ *                             at most 16; the table's arrays do not depend on the number)
+ *   MCX_TUNE_SUB_MIN          group size above which a group of the prefix index gets the
+ *                             second (anchor-gram) index (0 = default, 128)
+ *   MCX_TUNE_TILES_MIN        batch size from which the tile kernel (large batches) runs
+ *                             instead of the small-batch kernel; MCX_TUNE_AUTO = the library's
+ *                             own rule (more than 8192 strings, earlier for tables with very
+ *                             large groups)
+ *   MCX_TUNE_LIST_TWO_PASS    1: match lists by a counting and a filling pass always (the path
+ *                             otherwise taken only when a string is matched by more than 16
+ *                             distinct pattern texts)
+ */
+#define MCX_TUNE_COMPILE_THREADS 1
+#define MCX_TUNE_SUB_MIN 2
+#define MCX_TUNE_TILES_MIN 3
+#define MCX_TUNE_LIST_TWO_PASS 4
+#define MCX_TUNE_AUTO 0xFFFFFFFFFFFFFFFFull
+int mcx_ctx_tune(mcx_ctx *ctx, int knob, uint64_t value);
+
 /* device memory helpers for callers that have no HIP binding of their own */
 int mcx_dev_alloc(mcx_ctx *ctx, size_t bytes, void **d_out);
 int mcx_dev_free(mcx_ctx *ctx, void *d_ptr);

@@ -16,6 +16,8 @@ F_LOADED, F_BOUND, F_SAFE = 1, 2, 4
 O_HAS_HOLDERS, O_IN_USE, O_ROOT = 1, 2, 4
 CLOSURE_HOLDERS, CLOSURE_DEPS = 0, 1
 TABLE_NORMALIZE_DASH = 1
+TUNE_COMPILE_THREADS, TUNE_SUB_MIN, TUNE_TILES_MIN, TUNE_LIST_TWO_PASS = 1, 2, 3, 4
+TUNE_AUTO = 0xFFFFFFFFFFFFFFFF
 
 # packed device record of the fleet inventory (mcx_dev_rec_t, 16 bytes)
 DEV_REC = np.dtype([("subsystem", "u1"), ("devtype", "u1"), ("attrs", "u1"), ("iface_class", "u1"),
@@ -65,6 +67,7 @@ def load_library():
         "mcx_ctx_destroy": (None, [_vp]),
         "mcx_sync": (ctypes.c_int, [_vp]),
         "mcx_ctx_stream": (_vp, [_vp]),
+        "mcx_ctx_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_uint64]),
         "mcx_strerror": (ctypes.c_char_p, [ctypes.c_int]),
         "mcx_last_error": (ctypes.c_char_p, [_vp]),
         "mcx_dev_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
@@ -271,6 +274,20 @@ class Context:
         if rc != 0:
             detail = self.lib.mcx_last_error(self.h).decode(errors="replace")
             raise McxError(rc, what, detail or self.lib.mcx_strerror(rc).decode())
+
+    def tune(self, compile_threads=None, sub_min=None, tiles_min=None, list_two_pass=None):
+        """Tuning knobs for tables loaded after the call (none changes a result):
+        compile_threads (0 = one per core), sub_min (0 = default), tiles_min (batch size
+        from which the tile kernel runs; "auto" = the library's rule), list_two_pass."""
+        if compile_threads is not None:
+            self._check(self.lib.mcx_ctx_tune(self.h, TUNE_COMPILE_THREADS, int(compile_threads)), "mcx_ctx_tune")
+        if sub_min is not None:
+            self._check(self.lib.mcx_ctx_tune(self.h, TUNE_SUB_MIN, int(sub_min)), "mcx_ctx_tune")
+        if tiles_min is not None:
+            v = TUNE_AUTO if tiles_min == "auto" else int(tiles_min)
+            self._check(self.lib.mcx_ctx_tune(self.h, TUNE_TILES_MIN, v), "mcx_ctx_tune")
+        if list_two_pass is not None:
+            self._check(self.lib.mcx_ctx_tune(self.h, TUNE_LIST_TWO_PASS, int(bool(list_two_pass))), "mcx_ctx_tune")
 
     def sync(self):
         self._check(self.lib.mcx_sync(self.h), "mcx_sync")

@@ -21,11 +21,29 @@ struct mcx_matcher {
     uint16_t set;
 };
 
-/* one parsed pattern */
+/* one '*'-free piece of a pattern: a view into its pattern's matchers */
+struct mcx_seg {
+    const mcx_matcher *p;
+    size_t n;
+    size_t size() const { return n; }
+    const mcx_matcher &operator[](size_t k) const { return p[k]; }
+    const mcx_matcher *begin() const { return p; }
+    const mcx_matcher *end() const { return p + n; }
+};
+
+/* one parsed pattern: its matchers, segment after segment (two allocations a pattern: a
+ * table of millions of patterns is parsed in the time the allocator leaves) */
 struct mcx_pattern_ir {
-    std::vector<std::vector<mcx_matcher>> segs; /* segs[0] is the anchored one */
-    uint32_t flags = 0;                         /* MCX_PF_* */
+    std::vector<mcx_matcher> m;    /* all segments' matchers                      */
+    std::vector<uint32_t> seg_end; /* segment k = m[seg_end[k-1] .. seg_end[k])   */
+    uint32_t flags = 0;            /* MCX_PF_* */
     uint32_t minlen = 0;
+    size_t nsegs() const { return seg_end.size(); }
+    mcx_seg seg(size_t k) const /* seg(0) is the anchored one */
+    {
+        const size_t b = k ? seg_end[k - 1] : 0u;
+        return mcx_seg{m.data() + b, seg_end[k] - b};
+    }
 };
 
 struct mcx_compiled_table {
@@ -70,9 +88,18 @@ void mcx_emit_program(const mcx_pattern_ir &ir, uint32_t keylen, const std::vect
 void mcx_fill_slot(const mcx_pattern_ir &ir, uint32_t keylen, uint32_t orig, uint32_t mult,
                    const std::vector<uint32_t> &sets, uint32_t *slot, std::vector<uint32_t> &ext);
 
+/* threads: host threads the compile may use (0 = one per core, at most 16; small tables use
+ * fewer); sub_min: group size above which a group of the index gets the second (anchor-gram)
+ * index (0 = MCX_SUB_MIN).  Neither changes what a table matches; the arrays do not depend
+ * on the number of threads. */
+struct mcx_compile_options {
+    uint32_t threads = 0;
+    uint32_t sub_min = 0;
+};
+
 /* Whole table: parse, group by literal prefix, emit programs in group order
  * and build the hash index. */
-int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P,
-                      bool normalize_dash, mcx_compiled_table &out, std::string &err);
+int mcx_compile_table(const char *arena, const uint32_t *a_off, uint32_t P, bool normalize_dash,
+                      mcx_compiled_table &out, std::string &err, const mcx_compile_options *opt = nullptr);
 
 #endif

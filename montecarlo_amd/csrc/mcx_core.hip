@@ -171,6 +171,38 @@ void *mcx_ctx_stream(mcx_ctx *ctx)
     return ctx ? (void *)ctx->stream : nullptr;
 }
 
+int mcx_ctx_tune(mcx_ctx *ctx, int knob, uint64_t value)
+{
+    if (!ctx)
+        return MCX_E_BAD_ARG;
+    switch (knob) {
+    case MCX_TUNE_COMPILE_THREADS:
+        if (value > 64u) {
+            ctx->err = "MCX_TUNE_COMPILE_THREADS: at most 64";
+            return MCX_E_BAD_ARG;
+        }
+        ctx->tune_threads = (uint32_t)value;
+        return MCX_OK;
+    case MCX_TUNE_SUB_MIN:
+        if (value > 0xFFFFFFFFull) {
+            ctx->err = "MCX_TUNE_SUB_MIN: does not fit 32 bits";
+            return MCX_E_BAD_ARG;
+        }
+        ctx->tune_sub_min = (uint32_t)value;
+        return MCX_OK;
+    case MCX_TUNE_TILES_MIN:
+        ctx->tune_tiles_min_set = value != MCX_TUNE_AUTO;
+        ctx->tune_tiles_min = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value;
+        return MCX_OK;
+    case MCX_TUNE_LIST_TWO_PASS:
+        ctx->tune_two_pass = value != 0;
+        return MCX_OK;
+    default:
+        ctx->err = "unknown tuning knob";
+        return MCX_E_BAD_ARG;
+    }
+}
+
 int mcx_dev_alloc(mcx_ctx *ctx, size_t bytes, void **d_out)
 {
     if (!ctx || !d_out)

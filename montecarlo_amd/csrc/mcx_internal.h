@@ -49,9 +49,13 @@ struct mcx_ctx {
     uint32_t *d_amod = nullptr;
     uint8_t *d_hwtag = nullptr;
     uint64_t table_bytes = 0;
-    bool bulk_min_set = false;       /* MCX_BULK_MIN was in the environment when the table was loaded */
+    /* what mcx_ctx_tune left for the next table load, and what the loaded table took */
+    uint32_t tune_threads = 0, tune_sub_min = 0;
+    bool tune_tiles_min_set = false, tune_two_pass = false;
+    uint32_t tune_tiles_min = 0;
+    bool bulk_min_set = false;       /* the loaded table has a batch size of its own for the tile kernel */
     uint32_t bulk_min = 0;
-    bool list_two_pass = false;      /* MCX_LIST_TWO_PASS=1 when the table was loaded (test seam) */
+    bool list_two_pass = false;      /* match lists of the loaded table by count + fill always */
 
     /* dependency graph: forward CSR as given, reverse CSR built at load */
     uint32_t V = 0, E = 0;

@@ -2014,7 +2014,10 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
         return MCX_E_HIP;
     mcx_compiled_table t;
     std::string err;
-    int rc = mcx_compile_table(arena, a_off, P, (flags & MCX_TABLE_NORMALIZE_DASH) != 0, t, err);
+    mcx_compile_options copt;
+    copt.threads = ctx->tune_threads;
+    copt.sub_min = ctx->tune_sub_min;
+    int rc = mcx_compile_table(arena, a_off, P, (flags & MCX_TABLE_NORMALIZE_DASH) != 0, t, err, &copt);
     if (rc != 0) {
         ctx->err = err;
         return rc;
@@ -2051,13 +2054,9 @@ int mcx_alias_table_load(mcx_ctx *ctx, const char *arena, const uint32_t *a_off,
                        sizeof(mcx_slot_t) * (uint64_t)t.slots.size() + t.tags.size() +
                        sizeof(mcx_sub_t) * (uint64_t)t.sub.size() + t.sub_tags.size() + 4 * (uint64_t)P +
                        t.hw_tag.size();
-    {
-        const char *env = getenv("MCX_BULK_MIN");
-        ctx->bulk_min_set = env && *env;
-        ctx->bulk_min = ctx->bulk_min_set ? (uint32_t)strtoul(env, nullptr, 10) : 0u;
-        const char *two = getenv("MCX_LIST_TWO_PASS"); /* test seam: match lists by count + fill always */
-        ctx->list_two_pass = two && two[0] == '1';
-    }
+    ctx->bulk_min_set = ctx->tune_tiles_min_set;
+    ctx->bulk_min = ctx->tune_tiles_min;
+    ctx->list_two_pass = ctx->tune_two_pass;
     ctx->table_loaded = true;
     return MCX_OK;
 }

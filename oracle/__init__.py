@@ -71,11 +71,13 @@ def twin():
         lib.twin_alias_match.restype = ctypes.c_int
         lib.twin_alias_match.argtypes = [_vp, _vp, u32, _vp, _vp, u32, u32, ctypes.c_int, _vp, _vp]
         lib.twin_table_create.restype = _vp
-        lib.twin_table_create.argtypes = [_vp, _vp, u32, ctypes.c_int]
+        lib.twin_table_create.argtypes = [_vp, _vp, u32, ctypes.c_int, u32, u32]
         lib.twin_table_destroy.restype = None
         lib.twin_table_destroy.argtypes = [_vp]
         lib.twin_table_match.restype = ctypes.c_int
         lib.twin_table_match.argtypes = [_vp, _vp, _vp, u32, u32, _vp, _vp]
+        lib.twin_table_digest.restype = None
+        lib.twin_table_digest.argtypes = [_vp, _vp]
         _TWIN = lib
     return _TWIN
 
@@ -279,9 +281,11 @@ def device_filter(rec, drv_arena, drv_off, dev_off, max_per_host=0):
 class TwinTable:
     """the CPU twin's compiled table, kept between calls (indexed CPU baseline)"""
 
-    def __init__(self, arena, a_off, normalize_dash=False):
+    def __init__(self, arena, a_off, normalize_dash=False, threads=0, sub_min=0):
+        """threads / sub_min: the table compiler's options (0 = its defaults)"""
         a_off = np.ascontiguousarray(a_off, dtype=np.uint32)
-        self.h = twin().twin_table_create(_p(_c(arena, np.uint8)), _p(a_off), len(a_off) - 1, int(normalize_dash))
+        self.h = twin().twin_table_create(_p(_c(arena, np.uint8)), _p(a_off), len(a_off) - 1, int(normalize_dash),
+                                          int(threads), int(sub_min))
         if not self.h:
             raise RuntimeError("twin_table_create failed")
 

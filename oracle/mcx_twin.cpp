@@ -120,21 +120,71 @@ struct twin_table {
     bool normalize_dash;
 };
 
-void *twin_table_create(const char *arena, const uint32_t *a_off, uint32_t P, int normalize_dash)
+/* threads / sub_min: the compiler's options (0 = its defaults) */
+void *twin_table_create(const char *arena, const uint32_t *a_off, uint32_t P, int normalize_dash, uint32_t threads,
+                        uint32_t sub_min)
 {
     twin_table *tt = new twin_table();
     std::string err;
     tt->normalize_dash = normalize_dash != 0;
-    if (mcx_compile_table(arena, a_off, P, tt->normalize_dash, tt->t, err) != 0) {
+    mcx_compile_options opt;
+    opt.threads = threads;
+    opt.sub_min = sub_min;
+    if (mcx_compile_table(arena, a_off, P, tt->normalize_dash, tt->t, err, &opt) != 0) {
         delete tt;
         return nullptr;
     }
     return tt;
 }
 
+/* compile only: the return code and the error text (for tests of the error paths) */
+int twin_compile_error(const char *arena, const uint32_t *a_off, uint32_t P, uint32_t threads, char *msg, uint32_t cap)
+{
+    mcx_compiled_table t;
+    std::string err;
+    mcx_compile_options opt;
+    opt.threads = threads;
+    int rc = mcx_compile_table(arena, a_off, P, false, t, err, &opt);
+    if (msg && cap) {
+        strncpy(msg, err.c_str(), cap - 1);
+        msg[cap - 1] = 0;
+    }
+    return rc;
+}
+
 void twin_table_destroy(void *h)
 {
     delete (twin_table *)h;
+}
+
+/* FNV-1a digests of the arrays of a kept table, in the order slot, ext, sig, slots, tags, sub,
+ * sub_tags, lens, sets, dup_start, dup_idx, hw_tag, then {n_distinct, n_sub_groups, max_group, P}:
+ * what a change of the compiler (or of its number of threads) must leave alone */
+static uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; ++i)
+        h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
+void twin_table_digest(void *h, uint64_t out[13])
+{
+    const mcx_compiled_table &t = ((const twin_table *)h)->t;
+    out[0] = fnv(t.slot.data(), 4 * t.slot.size());
+    out[1] = fnv(t.ext.data(), 4 * t.ext.size());
+    out[2] = fnv(t.sig.data(), 4 * t.sig.size());
+    out[3] = fnv(t.slots.data(), sizeof(mcx_slot_t) * t.slots.size());
+    out[4] = fnv(t.tags.data(), t.tags.size());
+    out[5] = fnv(t.sub.data(), sizeof(mcx_sub_t) * t.sub.size());
+    out[6] = fnv(t.sub_tags.data(), t.sub_tags.size());
+    out[7] = fnv(t.lens.data(), 4 * t.lens.size());
+    out[8] = fnv(t.sets.data(), 4 * t.sets.size());
+    out[9] = fnv(t.dup_start.data(), 4 * t.dup_start.size());
+    out[10] = fnv(t.dup_idx.data(), 4 * t.dup_idx.size());
+    out[11] = fnv(t.hw_tag.data(), t.hw_tag.size());
+    const uint32_t n[4] = {t.n_distinct, t.n_sub_groups, t.max_group, t.P};
+    out[12] = fnv(n, sizeof n);
 }
 
 /* strings i0..i1 against a kept table; candidates come from the literal-prefix

@@ -90,14 +90,11 @@ while time.time() < t_end:
             sys.exit(0)
         rnd.sample(range(N), min(N, 3 if P > 20000 else 12))
         continue
-    # the two test seams of the library, drawn per case: the group size from which a group
+    # two tuning knobs of the library (mcx_ctx_tune), drawn per case: the group size from which a group
     # gets a second index, and the batch size from which the large-batch kernel runs
-    knobs = {"MCX_SUB_MIN": rnd.choice([None, None, "3", "20"]), "MCX_BULK_MIN": rnd.choice([None, None, "1", "100000000"])}
-    for k, v in knobs.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    knobs = {"MCX_SUB_MIN": rnd.choice([None, None, 3, 20]), "MCX_BULK_MIN": rnd.choice([None, None, 1, 100000000])}
+    ctx.tune(sub_min=knobs["MCX_SUB_MIN"] or 0, tiles_min="auto" if knobs["MCX_BULK_MIN"] is None else knobs["MCX_BULK_MIN"],
+             compile_threads=rnd.choice([0, 1, 3]))
     try:
         ctx.alias_table_load(A, a_off, np.zeros(P, dtype=np.uint32), flags=1 if norm else 0)
     except Exception as e:                     # noqa: BLE001 - a table kmod's rule refuses: skip

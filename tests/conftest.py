@@ -31,6 +31,14 @@ def gpu_ctx():
     ctx.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_knobs(request):
+    """a test that turned a tuning knob of the shared context does not leave it turned"""
+    yield
+    if "gpu_ctx" in request.fixturenames:
+        request.getfixturevalue("gpu_ctx").tune(compile_threads=0, sub_min=0, tiles_min="auto", list_two_pass=0)
+
+
 # ---- a fake sysfs / procfs tree for the scalar ABI (env MCX_SYSFS_ROOT) ------------
 
 def mkdev(root, devpath, bus, attrs=None, uevent="", driver=None):

@@ -124,7 +124,7 @@ def test_k1_match_lists(gpu_ctx, oracle_mod):
     assert off.tolist() == [0] and len(idx) == 0
 
 
-def test_k1_match_lists_long_and_both_ways(gpu_ctx, oracle_mod, monkeypatch):
+def test_k1_match_lists_long_and_both_ways(gpu_ctx, oracle_mod):
     """Lists come from one pass of the kernel while no string is matched by more than 16
     different pattern texts, and from a second, filling pass otherwise.  Both ways on the same
     batches (the seam forces the second one), a string matched by 17, by 40 and by more than
@@ -151,8 +151,8 @@ def test_k1_match_lists_long_and_both_ways(gpu_ctx, oracle_mod, monkeypatch):
     S, s_off = pack_strings(strs)
     o_off, o_idx = oracle_mod.alias_match_list(A, a_off, S, s_off)
     assert o_off[1] - o_off[0] > 10_000 and 16 < o_off[4] - o_off[3] <= 20
-    for two_pass in ("0", "1"):
-        monkeypatch.setenv("MCX_LIST_TWO_PASS", two_pass)
+    for two_pass in (0, 1):
+        gpu_ctx.tune(list_two_pass=two_pass)
         gpu_ctx.alias_table_load(A, a_off, np.zeros(len(pats), dtype=np.uint32))
         off, idx = gpu_ctx.alias_match_list(S, s_off)
         assert np.array_equal(off, o_off) and np.array_equal(idx, o_idx)
@@ -166,17 +166,17 @@ def test_k1_match_lists_long_and_both_ways(gpu_ctx, oracle_mod, monkeypatch):
         off, idx = gpu_ctx.alias_match_list(Ss, ss_off, K=2)
         w_off, w_idx = oracle_mod.alias_match_list(A, a_off, Ss, ss_off, K=2)
         assert np.array_equal(off, w_off) and np.array_equal(idx, w_idx)
-    monkeypatch.delenv("MCX_LIST_TWO_PASS")
+    gpu_ctx.tune(list_two_pass=0)
     # the synthetic table both ways: same lists
     P, N = 30000, 70000
     A, a_off, a_mod = synth.alias_table(21, P)
     S, s_off = synth.modalias_strings(21, P, N)
     got = []
-    for two_pass in ("0", "1"):
-        monkeypatch.setenv("MCX_LIST_TWO_PASS", two_pass)
+    for two_pass in (0, 1):
+        gpu_ctx.tune(list_two_pass=two_pass)
         gpu_ctx.alias_table_load(A, a_off, a_mod)
         got.append(gpu_ctx.alias_match_list(S, s_off))
-    monkeypatch.delenv("MCX_LIST_TWO_PASS")
+    gpu_ctx.tune(list_two_pass=0)
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     o_off, o_idx = oracle_mod.alias_match_list(A, a_off, S[: s_off[300]], s_off[:301])
     assert np.array_equal(got[0][0][:301], o_off) and np.array_equal(got[0][1][: o_off[300]], o_idx)
@@ -280,20 +280,20 @@ def test_k1_single_key_length_tables(gpu_ctx, oracle_mod, N):
 
 
 @pytest.mark.parametrize("sub_min,norm", [(3, False), (40, False), (3, True)])
-def test_k1_second_index_of_large_groups(gpu_ctx, oracle_mod, monkeypatch, sub_min, norm):
+def test_k1_second_index_of_large_groups(gpu_ctx, oracle_mod, sub_min, norm):
     """Large batches look large pattern groups up by the grams of the string.  With the
     size from which a group counts as large set low, the synthetic table has hundreds of
     such groups and a block meets more (string, group) pairs and runs than it has room
     for, so the whole-group way out is taken as well; first_idx, count and the match
     lists must not notice any of it."""
-    monkeypatch.setenv("MCX_SUB_MIN", str(sub_min))
+    gpu_ctx.tune(sub_min=sub_min)
     P, N = 30000, 70000
     A, a_off, a_mod = synth.alias_table(9, P)
     S, s_off = synth.modalias_strings(9, P, N)
     flags = 1 if norm else 0
     gpu_ctx.alias_table_load(A, a_off, a_mod, flags)
     first, count = gpu_ctx.alias_match(S, s_off)
-    monkeypatch.delenv("MCX_SUB_MIN")
+    gpu_ctx.tune(sub_min=0)
     t_first, t_count = oracle_mod.alias_match(A, a_off, S, s_off, normalize_dash=norm, use_twin=True)
     assert np.array_equal(first, t_first) and np.array_equal(count, t_count)
     check_glibc_sample(oracle_mod, A, a_off, S, s_off, first, count, 1000, normalize_dash=norm, seed=sub_min)
@@ -305,24 +305,25 @@ def test_k1_second_index_of_large_groups(gpu_ctx, oracle_mod, monkeypatch, sub_m
 
 
 @pytest.mark.parametrize("N", [1, 100, 2049, 5000, 8000, 12000])
-def test_k1_large_batch_kernel_on_small_batches(gpu_ctx, oracle_mod, monkeypatch, N):
+def test_k1_large_batch_kernel_on_small_batches(gpu_ctx, oracle_mod, N):
     """A table with a very large group sends every batch to the large-batch kernel; here
-    the batch-size seam does, so that it runs with one to eight strings per block (and the
+    the batch-size knob (mcx_ctx_tune) does, so that it runs with one to eight strings per block (and the
     small-batch kernel, which answers second, with one to eight as well)."""
-    monkeypatch.setenv("MCX_BULK_MIN", "1")
-    monkeypatch.setenv("MCX_SUB_MIN", "5")
+    gpu_ctx.tune(tiles_min=1, sub_min=5)
     P = 20000
     A, a_off, a_mod = synth.alias_table(11, P)
     S, s_off = synth.modalias_strings(11, P, N)
     gpu_ctx.alias_table_load(A, a_off, a_mod)
     first, count = gpu_ctx.alias_match(S, s_off)
     off, idx = gpu_ctx.alias_match_list(S, s_off)
-    monkeypatch.delenv("MCX_BULK_MIN")
     t_first, t_count = oracle_mod.alias_match(A, a_off, S, s_off, use_twin=True)
     assert np.array_equal(first, t_first) and np.array_equal(count, t_count)
     assert np.array_equal(np.diff(off.astype(np.int64)), count)
     check_glibc_sample(oracle_mod, A, a_off, S, s_off, first, count, 1000, seed=N)
-    # the other kernel, same answers
+    # the other kernel (the knobs belong to a table: loaded again), same answers
+    gpu_ctx.tune(tiles_min=10**9, sub_min=0)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    gpu_ctx.tune(tiles_min="auto")
     f2, c2 = gpu_ctx.alias_match(S, s_off)
     assert np.array_equal(first, f2) and np.array_equal(count, c2)
 

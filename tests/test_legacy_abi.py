@@ -8,6 +8,7 @@ this container's real /sys are those recorded from the reference itself when the
 survey ran it here (496-byte record, 7 candidate drivers, 6 virtio PCI devices)."""
 import ctypes
 import os
+import subprocess
 
 import pytest
 
@@ -217,6 +218,11 @@ def test_shipped_library_reads_no_environment(lib, product_lib, tree, tmp_path, 
     with open(os.path.join(os.path.dirname(__file__), "..", "montecarlo_amd", "lib", "libmontecarlo.so"), "rb") as f:
         blob = f.read()
     assert b"MCX_SYSFS_ROOT" not in blob and b"MCX_MODPROBE" not in blob and b"MCX_DMESG_CMD" not in blob
+    # no environment variable at all: the library does not import getenv (or its secure twin)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(os.path.dirname(__file__), "..", "montecarlo_amd",
+                                                                       "lib", "libmontecarlo.so")],
+                        capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in nm, [line for line in nm.splitlines() if "getenv" in line]
 
 
 def test_real_sysfs_matches_reference_probe(product_lib, monkeypatch):

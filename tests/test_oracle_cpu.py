@@ -367,3 +367,53 @@ def test_oracle_k2_golden(oracle_mod):
             clo, edges, levels = oracle_mod.dep_closure(rowptr, col, flags, seeds, direction)
             members = [v for v in range(c["V"]) if clo[v >> 5] >> (v & 31) & 1]
             assert members == c[key]["members"] and edges == c[key]["edges"] and levels == c[key]["levels"]
+
+
+def test_compiled_tables_are_what_they_were(oracle_mod):
+    """The table compiler runs on several host threads.  Every array it hands to the device
+    (slots, overflow bodies, signatures, both hash indexes and their tag bytes, key lengths,
+    bracket sets, the copies' positions, bus-tag bytes) is compared, by digest, with what the
+    single-threaded compiler produced before it was split (tests/golden/compile_digests.json,
+    tests/make_compile_digests.py) - with one thread and with thread counts that do not divide
+    anything evenly."""
+    import json
+
+    import make_compile_digests as mk
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "compile_digests.json")) as f:
+        gold = json.load(f)
+    assert len(gold) >= 9
+    for key, want in gold.items():
+        parts = key.split(":")
+        kind, seed, P, norm = parts[0], int(parts[1]), int(parts[2]), bool(int(parts[3]))
+        sub_min = int(parts[4][3:]) if len(parts) > 4 else None
+        for threads in (1, 3, 16):
+            got = mk.digest(kind, seed, P, norm, threads=threads, sub_min=sub_min)
+            assert got == want, (key, threads, [i for i in range(13) if got[i] != want[i]])
+
+
+def test_compile_errors_name_the_first_bad_pattern(oracle_mod):
+    """Whatever the number of threads, a refused table is refused for its first bad pattern."""
+    import ctypes
+
+    tw = oracle_mod.twin()
+    pats = [b"ok:%d*" % k for k in range(20000)]
+    pats[15000] = b"bad:[[:alpha:]]"
+    pats[4000] = b"bad:[[=a=]]"
+    A = np.frombuffer(b"".join(pats), dtype=np.uint8).copy()
+    a_off = np.zeros(len(pats) + 1, dtype=np.uint32)
+    a_off[1:] = np.cumsum([len(p) for p in pats])
+    tw.twin_compile_error.restype = ctypes.c_int
+    tw.twin_compile_error.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                      ctypes.c_char_p, ctypes.c_uint32]
+    for threads in (1, 2, 7):
+        buf = ctypes.create_string_buffer(256)
+        rc = tw.twin_compile_error(A.ctypes.data, a_off.ctypes.data, len(pats), threads, buf, 256)
+        assert rc == -5 and buf.value.startswith(b"pattern 4000:"), (threads, rc, buf.value)
+    # offsets that go backwards: the first such place is reported, unless a bad pattern comes first
+    off2 = a_off.copy()
+    off2[3001] = off2[3000] - 1
+    for threads in (1, 5):
+        buf = ctypes.create_string_buffer(256)
+        rc = tw.twin_compile_error(A.ctypes.data, off2.ctypes.data, len(pats), threads, buf, 256)
+        assert rc == -2 and b"not monotonic at pattern 3000" in buf.value, (threads, rc, buf.value)
