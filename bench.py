@@ -10,7 +10,8 @@ synthetic modalias strings already resident in HBM - configs[1] of the benchmark
   fleet         the fused inventory pipeline on configs[4] (100000 hosts, ~10M devices)
   configs3      1M strings x 3M patterns on this one GPU
 
---gpus N > 1 (launched through torch.distributed.run, one rank per GPU): configs[3], the alias
+--gpus N > 1 (one rank per GPU: launched through torch.distributed.run, or by this script itself
+as child processes when it is called without a launcher): configs[3], the alias
 table cut into N slices, all strings against every slice, MIN / SUM all-reduce over RCCL per
 step; the collective alone, the string-sharded layout and the one-GPU time are in the same line.
 
@@ -53,7 +54,48 @@ def parse():
     ap.add_argument("--fleet-devices", type=int, default=100, help="mean devices per host")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baselines (0 = every core this process may run on; where the "
+                         "box sets OMP_NUM_THREADS as its CPU share, that many)")
     return ap.parse_args()
+
+
+def host_cores():
+    """(cores this process may run on, threads the CPU baselines use).  On a shared machine the
+    affinity mask shows every core of the host while the job's share is what OMP_NUM_THREADS
+    says (the GPU boxes set it): more threads than the share only queue up."""
+    online = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    use = CPU_THREADS
+    if use <= 0:
+        try:
+            use = int(os.environ.get("OMP_NUM_THREADS", "0"))
+        except ValueError:
+            use = 0
+        use = min(online, use) if use > 0 else online
+    return online, max(1, min(use, 256))
+
+
+CPU_THREADS = 0
+
+
+def roofline_valu():
+    """The tile kernel's own roofline, from the SQ counters on file (profiles/k1_tiles_sq_counters.json,
+    10^6 strings x 30 000 patterns): the kernel is bound by instruction issue, not by HBM.
+    SQ_ACTIVE_INST_VALU counts in units of four cycles and SQ_BUSY_CYCLES once per shader engine
+    (32 of them); 1024 SIMDs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "k1_tiles_sq_counters.json")) as f:
+            rec = json.load(f)
+        c = rec["counters"]["k1_tiles_sq1"]
+        busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
+        return {"bound": "valu issue", "valu_busy_frac": busy, "lanes_active_of_64": lanes,
+                "frac_of_lane_throughput": busy * lanes / 64.0,
+                "valu_per_string": rec["derived"]["valu_instructions_per_string"],
+                "source": "profiles/k1_tiles_sq_counters.json (rocprofv3 --pmc on " + rec["workload"] + "), on file, "
+                          "not measured in this run"}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
 
 
 def k1_algorithmic_bytes(S, s_off, A, a_off):
@@ -97,7 +139,7 @@ def cpu_baseline_k1(A, a_off, S, s_off, budget_s):
     import oracle
 
     N, P = len(s_off) - 1, len(a_off) - 1
-    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()))
+    online, cores = host_cores()
     oracle.oracle()  # load before timing
     bounds = [N * k // cores for k in range(cores + 1)]
 
@@ -120,6 +162,8 @@ def cpu_baseline_k1(A, a_off, S, s_off, budget_s):
         "value": passes * N * P / el,
         "unit": "pairs/s",
         "cores": cores,
+        "threads_used": cores,
+        "cores_online": online,
         "kind": "port",
         "sample": f"{passes} whole passes of the same {N}x{P} workload, glibc fnmatch(p,s,0) double loop, "
                   f"{cores} threads over strings, {el:.1f} s",
@@ -178,8 +222,35 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    global CPU_THREADS
+    CPU_THREADS = args.cpu_threads
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        # Called without a launcher: start the ranks as child processes, one per GPU.  Nothing in
+        # this process has touched the GPU yet (torch is not even imported), which is the only
+        # time this is allowed; rank 0's line goes to the stdout the children inherit.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+    if os.environ.get("MCX_BENCH_DRYRUN") == "1":
+        # launch plumbing only (no GPU, no library): rendezvous over gloo, one line from rank 0
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.init_process_group("gloo")
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}))
+        return
 
     import torch
 
@@ -228,7 +299,10 @@ def bench_one_gpu(ctx, synth, args, torch, stream, fence, local_rank):
     N, P = args.strings, args.patterns
     A, a_off, a_mod = synth.alias_table(args.seed, P)
     S, s_off = synth.modalias_strings(args.seed, P, N)
+    ctx.alias_table_load(A, a_off, a_mod)   # the first load also pays for the code object
+    t0 = time.perf_counter()
     ctx.alias_table_load(A, a_off, a_mod)
+    table_load_ms = (time.perf_counter() - t0) * 1e3
     d_S, d_off = ctx.to_device(S), ctx.to_device(s_off)
     t_first = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
     t_count = torch.empty(N, dtype=torch.int32, device=f"cuda:{local_rank}")
@@ -286,6 +360,7 @@ def bench_one_gpu(ctx, synth, args, torch, stream, fence, local_rank):
             "device_us_per_launch": dev_s_per_launch * 1e6,
         },
         "matched_strings": int((count > 0).sum()),
+        "table_load_ms": table_load_ms,   # host compile of the table + upload, once per table
     }
     if not args.no_cpu:
         import oracle
@@ -383,12 +458,13 @@ def bench_configs3(ctx, synth, args, with_cpu=False):
         "frac_of_hbm_peak": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
         "matched_strings": int((count > 0).sum()),
         "host_seconds": {"generate_inputs": gen_s, "compile_and_load_table": load_s},
+        "roofline_valu": roofline_valu(),
     }
     if with_cpu:
         import oracle
 
         # glibc loop: about 0.1 s per string against 3M patterns; a sample on all cores, extrapolated
-        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        online, cores = host_cores()
         per = max(1, int(args.c3_cpu_strings) // cores)
         n_s = per * cores
         got = [None] * cores
@@ -408,11 +484,40 @@ def bench_configs3(ctx, synth, args, with_cpu=False):
         if not (np.array_equal(first[:n_s], o_first) and np.array_equal(count[:n_s], o_count)):
             raise SystemExit("bench: configs[3] result differs from the oracle")
         res["cpu_baseline"] = {
-            "value": n_s * P / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "value": n_s * P / el, "unit": "pairs/s", "cores": cores, "threads_used": cores, "cores_online": online,
+            "kind": "port",
             "sample": f"the first {n_s} of the {N} strings through the glibc fnmatch loop against all {P} "
                       f"patterns, {cores} threads, {el:.1f} s; EXTRAPOLATED to the whole batch: "
                       f"{el * N / n_s / 3600:.1f} hours",
             "extrapolated_seconds_per_pass": el * N / n_s,
+        }
+        # the fair CPU number: the same index, screen and matchers on the host cores (the twin), on
+        # 1 % of the strings, table compiled once and not timed
+        n_i = max(cores, N // 100)
+        t0 = time.perf_counter()
+        table = oracle.TwinTable(A, a_off)
+        compile_s = time.perf_counter() - t0
+        i_first = np.zeros(N, dtype=np.uint32)
+        i_count = np.zeros(N, dtype=np.uint32)
+        S8, s32 = np.ascontiguousarray(S, dtype=np.uint8), np.ascontiguousarray(s_off, dtype=np.uint32)
+        cut = [n_i * k // cores for k in range(cores + 1)]
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=table.match, args=(S8, s32, i_first, i_count, cut[k], cut[k + 1]))
+              for k in range(cores) if cut[k + 1] > cut[k]]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el_i = time.perf_counter() - t0
+        table.close()
+        if not (np.array_equal(first[:n_i], i_first[:n_i]) and np.array_equal(count[:n_i], i_count[:n_i])):
+            raise SystemExit("bench: configs[3] result differs from the indexed CPU twin")
+        res["cpu_baseline"]["indexed"] = {
+            "value": n_i * P / el_i, "unit": "pairs/s", "cores": cores,
+            "sample": f"the first {n_i} of the {N} strings (1 %) through the prefix index + gram screen + segment "
+                      f"matcher on the CPU, {cores} threads, {el_i:.2f} s (table compiled once in {compile_s:.1f} s, "
+                      f"not timed); EXTRAPOLATED to the whole batch: {el_i * N / n_i:.1f} s",
+            "extrapolated_seconds_per_pass": el_i * N / n_i,
         }
     for b in (d_S, d_off, d_f, d_c):
         b.free()
@@ -591,6 +696,11 @@ def bench_k2(ctx, synth, args, with_cpu=False):
                     "ids kept at 20 bits each (V <= 2^20), so its HBM traffic is below them",
         },
     }
+    moved = res["dep_flags"]["traffic"]
+    if moved:
+        # what the memory system really carried (PMC traffic on file) over the measured time
+        res["dep_flags"]["moved_GBs"] = moved / (flags_ms / 1e3) / 1e9
+        res["dep_flags"]["frac_moved"] = moved / (flags_ms / 1e3) / 1e9 / HBM_PEAK_GBS
     # closure: 16 seeds (what an operator asks for one device's drivers: latency bound) and the
     # large-frontier case, seeds = every BOUND module (in the deps direction that is the set of
     # modules that cannot be unloaded safely)
@@ -642,7 +752,7 @@ def bench_k2(ctx, synth, args, with_cpu=False):
         # the same flags from several threads, each counting the loaded holders of its own modules
         from concurrent.futures import ThreadPoolExecutor
 
-        threads = min(16, os.cpu_count() or 1)
+        online, threads = host_cores()
         cut = oracle.holders_cut(rrow, threads)
         with ThreadPoolExecutor(max_workers=threads) as pool:
             oracle.dep_flags_threads(rrow, rcol, flags, threads, pool, cut)
@@ -652,7 +762,7 @@ def bench_k2(ctx, synth, args, with_cpu=False):
                 oracle.dep_flags_threads(rrow, rcol, flags, threads, pool, cut)
                 n += 1
             ms = (time.perf_counter() - t0) * 1e3 / n
-        cpu["dep_flags_threads"] = {"cores": threads, "ms": ms, "edges_per_s": E / (ms / 1e3),
+        cpu["dep_flags_threads"] = {"cores": threads, "cores_online": online, "ms": ms, "edges_per_s": E / (ms / 1e3),
                                     "note": "over the graph of holders, built once and not timed"}
         for name, graph in (("closure_holders", (rrow, rcol)), ("closure_deps", (rowptr, col))):
             t0 = time.perf_counter()
@@ -702,6 +812,11 @@ def bench_fleet(ctx, synth, args, with_cpu=False):
                             d_roff.ptr, d_rid.ptr, total)
     ctx.sync()
     ms = (time.perf_counter() - t0) * 1e3 / reps
+    got_ids = d_rid.download(np.uint32, total)
+
+    def root_ids_head(n):
+        return got_ids[:n]
+
     d_f, d_c = ctx.alloc(4 * N), ctx.alloc(4 * N)
     ctx.alias_match_dev(d_S.ptr, d_soff.ptr, N, d_f.ptr, d_c.ptr)
     ctx.timer_begin()
@@ -733,23 +848,49 @@ def bench_fleet(ctx, synth, args, with_cpu=False):
     if with_cpu:
         import oracle
 
-        Hs = min(H, 500)
+        # hosts are independent: the per-host loop on every core, a range of hosts each
+        online, cores = host_cores()
+        Hs = min(H, 500 * cores)
         Ns = int(dev_off[Hs])
         hw = ctx.alias_hw_flags(V)
+        table = oracle.TwinTable(A, a_off)   # the alias part by the indexed twin, compiled once, not timed
+        S8, s32 = np.ascontiguousarray(S, dtype=np.uint8), np.ascontiguousarray(s_off, dtype=np.uint32)
+        f_s, c_s = np.zeros(N, dtype=np.uint32), np.zeros(N, dtype=np.uint32)
+        hcut = [Hs * k // cores for k in range(cores + 1)]
+        parts = [None] * cores
+
+        def hosts(k):
+            h0, h1 = hcut[k], hcut[k + 1]
+            if h1 <= h0:
+                return
+            i0, i1 = int(dev_off[h0]), int(dev_off[h1])
+            table.match(S8, s32, f_s, c_s, i0, i1)
+            f = f_s[i0:i1]
+            drv = np.where(f != 0xFFFFFFFF, a_mod[np.minimum(f, len(a_mod) - 1)], 0xFFFFFFFF).astype(np.uint32)
+            x0, x1 = int(extra_off[h0]), int(extra_off[h1])
+            parts[k] = oracle.fleet_roots(rowptr, col, drv, dev_off[h0: h1 + 1] - dev_off[h0],
+                                          extra_off[h0: h1 + 1] - extra_off[h0], extra_ids[x0:x1], safe, hw)
+
         t0 = time.perf_counter()
-        f_s, _ = oracle.alias_match(A, a_off, S[: s_off[Ns]], s_off[: Ns + 1], use_twin=True)
-        drv = np.where(f_s != 0xFFFFFFFF, a_mod[np.minimum(f_s, len(a_mod) - 1)], 0xFFFFFFFF).astype(np.uint32)
-        o_off, o_ids = oracle.fleet_roots(rowptr, col, drv, dev_off[: Hs + 1], extra_off[: Hs + 1],
-                                          extra_ids[: int(extra_off[Hs])], safe, hw)
+        th = [threading.Thread(target=hosts, args=(k,)) for k in range(cores)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
         fleet_s = time.perf_counter() - t0
+        table.close()
+        o_ids = np.concatenate([p[1] for p in parts if p is not None])
+        if not np.array_equal(o_ids, root_ids_head(o_ids.size)):
+            raise SystemExit("bench: fleet lists differ from the oracle")
         t0 = time.perf_counter()
         Nr = min(N, 1_000_000)
         Hr = int(np.searchsorted(dev_off, Nr, side="right")) - 1
         oracle.device_filter(rec[: int(dev_off[Hr])], arena, off, dev_off[: Hr + 1], 64)
         filt_s = time.perf_counter() - t0
-        cpu = {"cores": 1, "kind": "port",
-               "sample": f"first {Hs} hosts ({Ns} devices) through the per-host loop, alias part by the indexed "
-                         f"twin; device list predicates over the first {int(dev_off[Hr])} records",
+        cpu = {"cores": cores, "threads_used": cores, "cores_online": online, "kind": "port",
+               "sample": f"first {Hs} hosts ({Ns} devices) through the per-host loop, {cores} threads (a range of "
+                         f"hosts each), alias part by the indexed twin; device list predicates over the first "
+                         f"{int(dev_off[Hr])} records on one thread",
                "fleet_hosts_per_s": Hs / fleet_s, "fleet_devices_per_s": Ns / fleet_s,
                "device_filter_records_per_s": int(dev_off[Hr]) / filt_s}
     filter_bytes = 16 * N + 2 * N + 8 * (H + 1)
@@ -773,6 +914,7 @@ def bench_fleet(ctx, synth, args, with_cpu=False):
         "hosts_per_s": H / (ms / 1e3),
         "listed_modules": total,
         "alias_match_ms": k1_ms,
+        "roofline_valu": roofline_valu(),
         "pairs_per_s": N * P / (k1_ms / 1e3),
         "input_bytes": int(len(S) + 4 * (N + 1) + 4 * (H + 1) * 2 + 4 * X + V),
     }

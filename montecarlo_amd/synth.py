@@ -219,3 +219,80 @@ def device_records(seed, S, s_off):
     dt[~(is_usb | is_scsi)] = rng.integers(0, 7, size=int((~(is_usb | is_scsi)).sum()))
     rec["devtype"] = dt
     return rec
+
+
+def write_modules_dir(out, P=20000, seed=17, load_pm=300):
+    """A /lib/modules/<version>-like directory in the formats depmod writes, with synthetic
+    content: `modules.alias` ("alias <glob> <module>" lines in table order, '#' comments, blank
+    lines, lines with other keywords), `modules.dep` ("<path>: <everything it needs>" with
+    .ko / .ko.xz / .ko.zst / .ko.gz paths and dashed file names), and `proc_modules`, a
+    /proc/modules text of a loaded set that is closed under "needs".  Returns the module names
+    in id order (first appearance in modules.alias, then modules.dep)."""
+    os.makedirs(out, exist_ok=True)
+    A, a_off, a_mod = alias_table(seed, P)
+    V = alias_modules(P)
+    names, seen = [], set()
+    for m, name in enumerate(module_names(seed + 1, V)):
+        if name in seen:  # one file per module: a second "ext4" gets a number
+            name = f"{name}_{m:x}"
+        seen.add(name)
+        names.append(name)
+    raw = A.tobytes()
+    suffix = (".ko", ".ko.xz", ".ko.zst", ".ko.gz")
+    sub = ("kernel/drivers/net/ethernet/intel", "kernel/drivers/usb/serial", "kernel/sound/pci/hda", "kernel/fs/nls",
+           "updates/dkms")
+
+    def path_of(m):
+        # file names keep their dashes: the module name is the base name with '-' as '_'
+        fname = names[m].replace("_", "-") if m % 3 == 0 else names[m]
+        return f"{sub[m % len(sub)]}/{fname}{suffix[m % len(suffix)]}"
+
+    with open(os.path.join(out, "modules.alias"), "w") as f:
+        f.write("# Aliases extracted from modules themselves.\n")
+        for j in range(P):
+            if j % 997 == 5:
+                f.write("\n# a comment in the middle\n")
+            if j % 1499 == 7:
+                f.write(f"softdep {names[a_mod[j]]} pre: {names[(a_mod[j] + 1) % V]}\n")
+                f.write(f"options {names[a_mod[j]]} debug=1\n")
+            # the alias side may write the module with dashes as well (kmod folds them)
+            mod = names[a_mod[j]].replace("_", "-") if j % 11 == 0 else names[a_mod[j]]
+            f.write(f"alias {raw[a_off[j]:a_off[j + 1]].decode()} {mod}\n")
+        f.write(f"alias symbol:mcx_exported_symbol {names[0]}\n")
+    rowptr, col = dep_graph(seed + 2, V, 3)
+    closure = [None] * V
+
+    def needs(u):
+        # iterative: everything u needs, directly or not, nearest first
+        stack = [u]
+        while stack:
+            w = stack[-1]
+            if closure[w] is not None:
+                stack.pop()
+                continue
+            kids = [int(v) for v in col[rowptr[w]:rowptr[w + 1]]]
+            todo = [v for v in kids if closure[v] is None]
+            if todo:
+                stack.extend(todo)
+                continue
+            acc, seen = [], set()
+            for v in kids:
+                for x in [v] + closure[v]:
+                    if x not in seen:
+                        seen.add(x)
+                        acc.append(x)
+            closure[w] = acc
+            stack.pop()
+        return closure[u]
+
+    with open(os.path.join(out, "modules.dep"), "w") as f:
+        for u in range(V):
+            deps = " ".join(path_of(w) for w in needs(u))
+            f.write(f"{path_of(u)}:{' ' + deps if deps else ''}\n")
+    flags = dep_flags(seed + 3, rowptr, col, load_pm)
+    with open(os.path.join(out, "proc_modules"), "w") as f:
+        for u in range(V):
+            if flags[u] & 1:
+                f.write(f"{names[u]} {16384 + 4096 * (u % 50)} 0 - Live 0x0000000000000000\n")
+        f.write("not_in_the_tables 16384 0 - Live 0x0000000000000000\n")
+    return names

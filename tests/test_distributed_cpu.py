@@ -110,3 +110,28 @@ def test_gloo_ranks_combine(tmp_path, oracle_mod, world):
         assert np.array_equal(np.load(tmp_path / f"list_idx_{r}.npy"), o_idx.astype(np.int64))
         assert np.array_equal(np.load(tmp_path / f"fleet_off_{r}.npy"), np.concatenate([[0], np.cumsum(sizes)]))
         assert np.array_equal(np.load(tmp_path / f"fleet_ids_{r}.npy"), want_ids)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks as child processes (before
+    anything touches the GPU) and passes rank 0's line through; under torch.distributed.run it
+    is a rank itself.  MCX_BENCH_DRYRUN=1 stops each rank after the rendezvous, so this runs
+    without a GPU."""
+    import json
+    import subprocess
+    import sys
+
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = dict(os.environ, MCX_BENCH_DRYRUN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "5", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 1
+    # one GPU: no children, same process
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1

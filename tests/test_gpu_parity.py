@@ -473,27 +473,53 @@ def _instance_of(pattern, rng):
     return bytes(out)
 
 
-def test_k1_real_host_tables(gpu_ctx, oracle_mod):
-    """configs[0]: the tables of the running kernel, where the box has them.  modules.alias and
-    modules.dep of /lib/modules/$(uname -r) go through the text loader into the kernels with
-    kmod's dash rule; every modalias sysfs shows plus 10 000 strings made from the table's own
-    patterns are resolved on the GPU and by glibc fnmatch, and up to 50 of them by kmod itself
-    (`modprobe -R`, which reads the binary index of the same directory)."""
+def _parse_modules_alias(text):
+    """modules.alias by hand, independent of the library's loader: (patterns, module names) in file order"""
+    pats, mods = [], []
+    for line in text.split(b"\n"):
+        tok = line.split()
+        if len(tok) >= 3 and tok[0] == b"alias":
+            pats.append(tok[1])
+            mods.append(tok[2].replace(b"-", b"_").decode())
+    return pats, mods
+
+
+def test_k1_real_host_tables(gpu_ctx, oracle_mod, tmp_path):
+    """configs[0]: kmod's table files through the text loader into the kernels.  Where the box
+    has /lib/modules/$(uname -r)/modules.alias and modules.dep (or MCX_TEST_MODULES_DIR names a
+    directory that has them) those are used; where it has none - the GPU boxes of this pool -
+    a directory in the REAL formats with SYNTHETIC content is written first
+    (synth.write_modules_dir: comments, lines with other keywords, .ko / .ko.xz / .ko.zst /
+    .ko.gz paths, dashed file names, a /proc/modules text), so that the flow never goes
+    untested: load_dir -> kernels with kmod's dash rule -> every string against glibc fnmatch
+    -> dependency flags and closure against the oracle -> the modules of a modalias in kmod's
+    order.  Strings: every modalias sysfs shows plus 10 000 made from the table's own patterns;
+    up to 50 of them also go to kmod itself (`modprobe -R`) where the directory has its binary
+    index."""
     import glob
     import shutil
     import subprocess
 
     from montecarlo_amd import ModTab
 
-    # MCX_TEST_MODULES_DIR: another directory with the two files (to run this test where the box has none)
     d = os.environ.get("MCX_TEST_MODULES_DIR") or os.path.join("/lib/modules", os.uname().release)
+    proc_modules = "/proc/modules"
     if not (os.path.isfile(os.path.join(d, "modules.alias")) and os.path.isfile(os.path.join(d, "modules.dep"))):
-        pytest.skip(f"no modules.alias / modules.dep under {d}: this box has no kernel module tables")
+        d = str(tmp_path / "modules")
+        synth.write_modules_dir(d, P=20000, seed=17)
+        proc_modules = os.path.join(d, "proc_modules")
     tab = ModTab()
     tab.load_dir(d)
     A, a_off, a_mod = tab.alias_arrays()
     P = len(a_off) - 1
     assert P > 0
+    # the loader against a parse by hand: same patterns, same owners, file order
+    with open(os.path.join(d, "modules.alias"), "rb") as f:
+        h_pats, h_mods = _parse_modules_alias(f.read())
+    raw = A.tobytes()
+    assert P == len(h_pats)
+    assert all(raw[a_off[j]:a_off[j + 1]] == h_pats[j] for j in range(P))
+    assert all(tab.module_name(int(a_mod[j])) == h_mods[j] for j in range(0, P, 7))
     strs = []
     for path in glob.glob("/sys/bus/*/devices/*/modalias"):
         try:
@@ -505,7 +531,6 @@ def test_k1_real_host_tables(gpu_ctx, oracle_mod):
             strs.append(t)
     n_sys = len(strs)
     rng = np.random.default_rng(1)
-    raw = A.tobytes()
     for j in rng.choice(P, size=10_000):
         t = _instance_of(raw[a_off[j]:a_off[j + 1]], rng)
         if t and b"\0" not in t:
@@ -516,17 +541,32 @@ def test_k1_real_host_tables(gpu_ctx, oracle_mod):
     o_first, o_count = oracle_mod.alias_match_sample(A, a_off, S, s_off, range(len(strs)), normalize_dash=True)
     assert np.array_equal(first, o_first) and np.array_equal(count, o_count)
     assert (count[n_sys:] > 0).mean() > 0.5          # most made-up strings do match their pattern
+    # the modules of a modalias, in kmod's order (all matching lines, file order), from the
+    # hand-parsed file and glibc: names, not ids, so the loader's numbering is covered too
+    hA, ha_off = pack_strings(h_pats)
+    pick = [int(i) for i in np.nonzero(count > 1)[0][:40]] + [int(i) for i in np.nonzero(count == 1)[0][:10]]
+    pS, ps_off = pack_strings([strs[i] for i in pick])
+    off, idx = gpu_ctx.alias_match_list(pS, ps_off)
+    w_off, w_idx = oracle_mod.alias_match_list(hA, ha_off, pS, ps_off, normalize_dash=True)
+    assert np.array_equal(off, w_off) and np.array_equal(idx, w_idx)
+    for k in range(len(pick)):
+        got = [tab.module_name(int(a_mod[j])) for j in idx[off[k]:off[k + 1]]]
+        assert got == [h_mods[j] for j in w_idx[w_off[k]:w_off[k + 1]]]
     # the dependency side of the same directory: flags and closure against the oracle
     rowptr, col = tab.dep_arrays(direct=True)
     V = len(rowptr) - 1
     if V:
         flags = np.full(V, 5, dtype=np.uint8)
-        if os.path.isfile("/proc/modules"):
-            with open("/proc/modules", "rb") as f:
+        if os.path.isfile(proc_modules):
+            with open(proc_modules, "rb") as f:
                 loaded, _ = tab.mark_loaded(f.read())
             flags = np.where(loaded & 1, 5, 4).astype(np.uint8)
+            if proc_modules != "/proc/modules":
+                assert 0 < int((loaded & 1).sum()) < V
         seeds = np.zeros((V + 31) // 32, dtype=np.uint32)
         seeds[0] = 1
+        lo = np.nonzero(flags & 1)[0][:64]
+        seeds[lo // 32] |= (1 << (lo % 32)).astype(np.uint32)
         check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
     modprobe = shutil.which("modprobe")
     if modprobe and os.path.isfile(os.path.join(d, "modules.alias.bin")):
