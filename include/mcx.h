@@ -272,8 +272,11 @@ int mcx_safe_table_sizes(uint32_t *n_core, uint32_t *n_prefix);
  * refused (MCX_E_BAD_ARG).
  * Device memory: 8 * V * ceil(H/32) bytes of scratch; a fleet that does not fit
  * is split by the caller into groups of hosts (hosts are independent).
- * Every listed module is idle in the sense of mc_driver_is_in_use
- * (montecarlo/libmontecarlo.c:573-725): it drives no device and has no holder.
+ * In this mode (used = what the modaliases resolve to) a listed module drives no
+ * device the batch knows of and has no holder.  The reference goes on to label
+ * every listed module "(In Use)" or "(Idle)" with mc_driver_is_in_use
+ * (desktop/ui.py:1579-1590), which looks at ALL device links of the host; the
+ * *_labeled entry points below return that byte.
  */
 int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N,
                     const uint32_t *dev_off, uint32_t H,
@@ -322,6 +325,52 @@ int mcx_fleet_roots_bound_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off
 int mcx_driver_modules(const char *drv_arena, const uint32_t *drv_off, uint32_t D,
                        const char *mod_names, const uint32_t *mod_off, uint32_t V,
                        uint32_t *drv_mod);
+
+/*
+ * The "(In Use)" / "(Idle)" label of the dashboard's module rows.  The reference asks
+ * mc_driver_is_in_use(module) for every module it lists (desktop/ui.py:1579-1590).  That
+ * function (montecarlo/libmontecarlo.c:573-725) answers 1 when a device link stands under
+ * /sys/bus/pci/drivers/<n>, /sys/bus/usb/drivers/<n> or /sys/bus/pcmcia/drivers/<n> for n =
+ * the module's name or its name variant (get_driver_names, libmontecarlo.c:538-566:
+ * rtw88_X -> rtw_X, else rtlX -> rtw_X), or when the module has holders (a listed module
+ * has none).  It looks at every device of the host: also the bridges, hubs and host
+ * controllers mc_list_all_devices leaves out and the devices behind the list's limit, none
+ * of which reach used_drivers.  So a listed module is "(In Use)" when its driver is bound
+ *   - under the variant name (module rtw88_8821cu, driver rtw_8821cu: the names differ, so
+ *     ui.py:1567 does not take the module for a used driver),
+ *   - only to devices the list does not show.
+ *
+ * mcx_driver_marks: the map from driver names to the modules they mark, CSR by driver
+ * number (mark_off: D + 1 entries; module ids ascending within a driver): driver d marks
+ * module m iff d's name equals m's name or m's name variant (the [name_variant] rules of
+ * the active tables; names cut at 127 bytes like the reference's buffers; a module without
+ * a name marks nothing).  *total_out = mark_off[D]; MCX_E_TOO_LARGE (offsets and total
+ * filled in) when mark_ids (cap entries) is too small.  Host only, no context needed.
+ */
+int mcx_driver_marks(const char *drv_arena, const uint32_t *drv_off, uint32_t D,
+                     const char *mod_names, const uint32_t *mod_off, uint32_t V,
+                     uint32_t *mark_off, uint32_t *mark_ids, uint64_t cap, uint64_t *total_out);
+/*
+ * mcx_fleet_roots_bound with labels: host h's marked modules are
+ * inuse_ids[inuse_off[h] .. inuse_off[h+1]) - for every device of the host on the pci, usb
+ * or pcmcia bus that has a driver bound, listed or not, the modules mcx_driver_marks names
+ * for that driver (repeats allowed, ids >= V ignored).  root_in_use[k] = 1 iff module
+ * root_ids[k] is marked on its host, else 0; needs cap bytes.  Y = inuse_off[H].
+ */
+int mcx_fleet_roots_labeled(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N,
+                            const uint32_t *dev_off, uint32_t H,
+                            const uint32_t *extra_off, const uint32_t *extra_ids,
+                            const uint8_t *safe_name, const uint32_t *bound_mod,
+                            const uint32_t *inuse_off, const uint32_t *inuse_ids,
+                            uint32_t *root_off, uint32_t *root_ids, uint8_t *root_in_use, uint64_t cap,
+                            uint64_t *total_out);
+int mcx_fleet_roots_labeled_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N,
+                                const void *d_dev_off, uint32_t H,
+                                const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                                const void *d_safe_name, const void *d_bound_mod,
+                                const void *d_inuse_off, const void *d_inuse_ids, uint32_t Y,
+                                void *d_root_off, void *d_root_ids, void *d_root_in_use, uint64_t cap,
+                                uint64_t *total_out);
 
 /* ---- fleet inventory: which devices a host would list --------------------- */
 
@@ -441,6 +490,19 @@ int mcx_fleet_inventory_roots_bound_dev(mcx_ctx *ctx, const void *d_rec, const v
                                         const void *d_extra_off, const void *d_extra_ids, uint32_t X,
                                         const void *d_safe_name, void *d_verdict,
                                         void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out);
+
+/* The same with the "(In Use)" byte of every listed module (see mcx_driver_marks): the marks
+ * come from the records themselves - every record of a host on the pci, usb or pcmcia bus
+ * with a driver bound, whether the device list shows it or not - through d_mark_off /
+ * d_mark_ids, the output of mcx_driver_marks for the driver-name table, on the device. */
+int mcx_fleet_inventory_roots_labeled_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
+                                          uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                                          const void *d_drv_mod, const void *d_mark_off, const void *d_mark_ids,
+                                          const void *d_dev_off, uint32_t H, uint32_t max_per_host,
+                                          const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                                          const void *d_safe_name, void *d_verdict,
+                                          void *d_root_off, void *d_root_ids, void *d_root_in_use, uint64_t cap,
+                                          uint64_t *total_out);
 
 /* ---- the library's name tables as data ------------------------------------ */
 

@@ -24,6 +24,7 @@ from .binding import (  # noqa: F401
     TABLE_NORMALIZE_DASH,
     safe_module_names,
     driver_modules,
+    driver_marks,
     pack_strings,
     DEV_REC,
     tables_load,

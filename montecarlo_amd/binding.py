@@ -185,6 +185,27 @@ def load_library():
              ctypes.POINTER(ctypes.c_uint64)],
         ),
         "mcx_driver_modules": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp]),
+        "mcx_driver_marks": (
+            ctypes.c_int,
+            [_vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint64,
+             ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_fleet_roots_labeled": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+             ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_fleet_roots_labeled_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp,
+             ctypes.c_uint32, _vp, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)],
+        ),
+        "mcx_fleet_inventory_roots_labeled_dev": (
+            ctypes.c_int,
+            [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, ctypes.c_uint32,
+             ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64,
+             ctypes.POINTER(ctypes.c_uint64)],
+        ),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -457,6 +478,42 @@ class Context:
         self._check(rc, "mcx_fleet_roots_bound")
         return root_off, ids[: total.value]
 
+    def fleet_roots_labeled(self, S, s_off, dev_off, extra_off, extra_ids, safe_name, bound_mod, inuse_off,
+                            inuse_ids):
+        """mcx_fleet_roots_labeled: (root_off, root_ids, root_in_use); host h's marked modules are
+        inuse_ids[inuse_off[h]:inuse_off[h+1]] (see driver_marks)"""
+        S, s_off = _as(S, np.uint8), _as(s_off, np.uint32)
+        dev_off, extra_off = _as(dev_off, np.uint32), _as(extra_off, np.uint32)
+        extra_ids, safe_name, bound_mod = _as(extra_ids, np.uint32), _as(safe_name, np.uint8), _as(bound_mod, np.uint32)
+        inuse_off, inuse_ids = _as(inuse_off, np.uint32), _as(inuse_ids, np.uint32)
+        N, H = len(s_off) - 1, len(dev_off) - 1
+        if len(extra_off) != H + 1 or len(inuse_off) != H + 1 or len(safe_name) != self.V or len(bound_mod) != N:
+            raise ValueError("extra_off and inuse_off need H+1 entries, safe_name V entries, bound_mod N entries")
+        root_off = np.zeros(H + 1, dtype=np.uint32)
+        total = ctypes.c_uint64()
+        args = (self.h, _ptr(S), _ptr(s_off), N, _ptr(dev_off), H, _ptr(extra_off), _ptr(extra_ids),
+                _ptr(safe_name), _ptr(bound_mod), _ptr(inuse_off), _ptr(inuse_ids), _ptr(root_off))
+        rc = self.lib.mcx_fleet_roots_labeled(*args, None, None, 0, ctypes.byref(total))
+        if rc not in (0, -6):
+            self._check(rc, "mcx_fleet_roots_labeled")
+        n = total.value
+        ids, use = np.zeros(max(n, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint8)
+        if n:
+            self._check(self.lib.mcx_fleet_roots_labeled(*args, _ptr(ids), _ptr(use), n, ctypes.byref(total)),
+                        "mcx_fleet_roots_labeled")
+        return root_off, ids[:n], use[:n]
+
+    def fleet_roots_labeled_dev(self, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe, d_bound_mod,
+                                d_inuse_off, d_inuse_ids, Y, d_root_off, d_root_ids, d_root_in_use, cap,
+                                size_only=False):
+        total = ctypes.c_uint64()
+        rc = self.lib.mcx_fleet_roots_labeled_dev(self.h, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X,
+                                                  d_safe, d_bound_mod, d_inuse_off, d_inuse_ids, Y, d_root_off,
+                                                  d_root_ids, d_root_in_use, cap, ctypes.byref(total))
+        if not (size_only and rc == -6 and cap < total.value < 2**32):
+            self._check(rc, "mcx_fleet_roots_labeled_dev")
+        return total.value
+
     def fleet_roots_dev(self, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe, d_root_off,
                         d_root_ids, cap, size_only=False):
         """returns the total; with size_only a too-small root_ids is not an error"""
@@ -556,6 +613,45 @@ class Context:
         if not (size_only and rc == -6 and cap < total.value < 2**32):
             self._check(rc, "mcx_fleet_inventory_roots_bound_dev")
         return total.value
+
+
+    def fleet_inventory_roots_labeled_dev(self, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, d_drv_mod,
+                                          d_mark_off, d_mark_ids, d_dev_off, H, max_per_host, d_extra_off,
+                                          d_extra_ids, X, d_safe, d_verdict, d_root_off, d_root_ids, d_root_in_use,
+                                          cap, size_only=False):
+        """the bound-driver inventory call with the "(In Use)" byte of every listed module (d_mark_off /
+        d_mark_ids: driver_marks of the driver-name table, on the device)"""
+        total = ctypes.c_uint64()
+        rc = self.lib.mcx_fleet_inventory_roots_labeled_dev(self.h, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D,
+                                                            d_drv_mod, d_mark_off, d_mark_ids, d_dev_off, H,
+                                                            int(max_per_host), d_extra_off, d_extra_ids, X, d_safe,
+                                                            d_verdict, d_root_off, d_root_ids, d_root_in_use, cap,
+                                                            ctypes.byref(total))
+        if not (size_only and rc == -6 and cap < total.value < 2**32):
+            self._check(rc, "mcx_fleet_inventory_roots_labeled_dev")
+        return total.value
+
+
+def driver_marks(driver_names, module_names):
+    """(mark_off, mark_ids): the modules each driver name marks "(In Use)" - those named like it
+    and those whose name variant (rtw88_X -> rtw_X, rtlX -> rtw_X) it is"""
+    lib = load_library()
+    d_arena, d_off = pack_strings([n.encode() if isinstance(n, str) else n for n in driver_names])
+    m_arena, m_off = pack_strings([n.encode() if isinstance(n, str) else n for n in module_names])
+    D = len(driver_names)
+    mark_off = np.zeros(D + 1, dtype=np.uint32)
+    total = ctypes.c_uint64()
+    args = (_ptr(d_arena) if len(d_arena) else None, _ptr(d_off), D, _ptr(m_arena) if len(m_arena) else None,
+            _ptr(m_off), len(module_names), _ptr(mark_off))
+    rc = lib.mcx_driver_marks(*args, None, 0, ctypes.byref(total))
+    if rc not in (0, -6):
+        raise McxError(rc, "mcx_driver_marks")
+    ids = np.zeros(max(total.value, 1), dtype=np.uint32)
+    if total.value:
+        rc = lib.mcx_driver_marks(*args, _ptr(ids), total.value, ctypes.byref(total))
+        if rc != 0:
+            raise McxError(rc, "mcx_driver_marks")
+    return mark_off, ids[: total.value]
 
 
 def driver_modules(driver_names, module_names):

@@ -371,12 +371,15 @@ dv_bound_of_kept(const mcx_dev_rec_t *__restrict__ rec, const uint32_t *__restri
     bound[k] = d < D ? drv_mod[d] : MCX_NO_MATCH;
 }
 
-/* d_drv_mod == nullptr: used drivers from the alias match; otherwise from the records' bound drivers */
+/* d_drv_mod == nullptr: used drivers from the alias match; otherwise from the records' bound drivers.
+ * d_root_in_use != nullptr (bound mode only): the "(In Use)" byte of every listed module, from the
+ * bound drivers of ALL the hosts' records on the pci / usb / pcmcia buses through d_mark_off / d_mark_ids */
 static int inventory_roots(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off, uint32_t N,
                            const void *d_drv_arena, const void *d_drv_off, uint32_t D, const void *d_drv_mod,
+                           const void *d_mark_off, const void *d_mark_ids,
                            const void *d_dev_off, uint32_t H, uint32_t max_per_host, const void *d_extra_off,
                            const void *d_extra_ids, uint32_t X, const void *d_safe_name, void *d_verdict,
-                           void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out)
+                           void *d_root_off, void *d_root_ids, void *d_root_in_use, uint64_t cap, uint64_t *total_out)
 {
     if (!ctx || !d_s_off || !d_dev_off || !d_root_off || !total_out || (N && !d_verdict))
         return MCX_E_BAD_ARG;
@@ -422,9 +425,17 @@ static int inventory_roots(mcx_ctx *ctx, const void *d_rec, const void *d_S, con
             (const mcx_dev_rec_t *)d_rec, (const uint32_t *)(tmp + o_src), (uint32_t)kept,
             (const uint32_t *)d_drv_mod, D, (uint32_t *)(tmp + o_bound));
     HIPCHK(ctx, hipGetLastError());
-    return mcx_fleet_roots_bound_dev(ctx, tmp, tmp + o_soff, (uint32_t)kept, tmp + o_kept, H, d_extra_off,
-                                     d_extra_ids, X, d_safe_name, tmp + o_bound, d_root_off, d_root_ids, cap,
-                                     total_out);
+    mcx_fleet_labels lab;
+    lab.rec = (const mcx_dev_rec_t *)d_rec; /* every record, listed or not */
+    lab.rec_off = (const uint32_t *)d_dev_off;
+    lab.n_rec = N;
+    lab.mark_off = (const uint32_t *)d_mark_off;
+    lab.mark_ids = (const uint32_t *)d_mark_ids;
+    lab.D = D;
+    lab.root_in_use = (uint8_t *)d_root_in_use;
+    return mcx_fleet_roots_enqueue(ctx, tmp, tmp + o_soff, (uint32_t)kept, tmp + o_kept, H, d_extra_off, d_extra_ids,
+                                   X, d_safe_name, kept ? tmp + o_bound : nullptr, d_root_in_use ? &lab : nullptr,
+                                   d_root_off, d_root_ids, cap, total_out);
 }
 
 int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
@@ -434,9 +445,9 @@ int mcx_fleet_inventory_roots_dev(mcx_ctx *ctx, const void *d_rec, const void *d
                                   const void *d_safe_name, void *d_verdict, void *d_root_off, void *d_root_ids,
                                   uint64_t cap, uint64_t *total_out)
 {
-    return inventory_roots(ctx, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, nullptr, d_dev_off, H,
-                           max_per_host, d_extra_off, d_extra_ids, X, d_safe_name, d_verdict, d_root_off, d_root_ids,
-                           cap, total_out);
+    return inventory_roots(ctx, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, nullptr, nullptr, nullptr, d_dev_off,
+                           H, max_per_host, d_extra_off, d_extra_ids, X, d_safe_name, d_verdict, d_root_off,
+                           d_root_ids, nullptr, cap, total_out);
 }
 
 int mcx_fleet_inventory_roots_bound_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
@@ -450,8 +461,83 @@ int mcx_fleet_inventory_roots_bound_dev(mcx_ctx *ctx, const void *d_rec, const v
         return MCX_E_BAD_ARG;
     /* D == 0: every device is unbound; any non-null pointer selects the mode, nothing is read through it */
     return inventory_roots(ctx, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, d_drv_mod ? d_drv_mod : d_rec,
-                           d_dev_off, H, max_per_host, d_extra_off, d_extra_ids, X, d_safe_name, d_verdict,
-                           d_root_off, d_root_ids, cap, total_out);
+                           nullptr, nullptr, d_dev_off, H, max_per_host, d_extra_off, d_extra_ids, X, d_safe_name,
+                           d_verdict, d_root_off, d_root_ids, nullptr, cap, total_out);
+}
+
+int mcx_fleet_inventory_roots_labeled_dev(mcx_ctx *ctx, const void *d_rec, const void *d_S, const void *d_s_off,
+                                          uint32_t N, const void *d_drv_arena, const void *d_drv_off, uint32_t D,
+                                          const void *d_drv_mod, const void *d_mark_off, const void *d_mark_ids,
+                                          const void *d_dev_off, uint32_t H, uint32_t max_per_host,
+                                          const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                                          const void *d_safe_name, void *d_verdict, void *d_root_off,
+                                          void *d_root_ids, void *d_root_in_use, uint64_t cap, uint64_t *total_out)
+{
+    if ((D && (!d_drv_mod || !d_mark_off || !d_mark_ids)) || (N && !d_rec) || (cap && !d_root_in_use))
+        return MCX_E_BAD_ARG;
+    return inventory_roots(ctx, d_rec, d_S, d_s_off, N, d_drv_arena, d_drv_off, D, d_drv_mod ? d_drv_mod : d_rec,
+                           d_mark_off, d_mark_ids, d_dev_off, H, max_per_host, d_extra_off, d_extra_ids, X,
+                           d_safe_name, d_verdict, d_root_off, d_root_ids, cap ? d_root_in_use : nullptr, cap,
+                           total_out);
+}
+
+/* host: the modules a bound driver's name stands for in mc_driver_is_in_use
+ * (reference montecarlo/libmontecarlo.c:573-725): that function looks for device links under
+ * /sys/bus/{pci,usb,pcmcia}/drivers/<n> with n = the module's name and, through get_driver_names
+ * (:538-566), its name variant - rtw88_X -> rtw_X, else rtlX -> rtw_X (the active table's
+ * [name_variant] rules; names cut at 127 bytes as the reference's buffers cut them).  Seen from
+ * the driver: driver name d marks module m iff d is m's name or m's variant; a module without a
+ * name marks nothing (:575).  CSR by driver number, module ids ascending within a driver. */
+int mcx_driver_marks(const char *drv_arena, const uint32_t *drv_off, uint32_t D, const char *mod_names,
+                     const uint32_t *mod_off, uint32_t V, uint32_t *mark_off, uint32_t *mark_ids, uint64_t cap,
+                     uint64_t *total_out)
+{
+    if (!mark_off || !total_out || (D && !drv_off) || (V && !mod_off) || (cap && !mark_ids))
+        return MCX_E_BAD_ARG;
+    for (uint32_t d = 0; d < D; ++d)
+        if (drv_off[d + 1] < drv_off[d])
+            return MCX_E_BAD_ARG;
+    for (uint32_t v = 0; v < V; ++v)
+        if (mod_off[v + 1] < mod_off[v])
+            return MCX_E_BAD_ARG;
+    if ((D && drv_off[D] && !drv_arena) || (V && mod_off[V] && !mod_names))
+        return MCX_E_BAD_ARG;
+    const mcx_tables_view *tv = mcx_tables_active();
+    std::unordered_map<std::string, std::vector<uint32_t>> by_name; /* a name a driver may carry -> modules */
+    by_name.reserve(2 * (size_t)V);
+    for (uint32_t v = 0; v < V; ++v) {
+        std::string name(mod_names + mod_off[v], mod_off[v + 1] - mod_off[v]);
+        if (name.empty())
+            continue;
+        std::string first = name.substr(0, 127);
+        by_name[first].push_back(v);
+        for (uint32_t k = 0; k + 1 < tv->count[MCX_TS_VARIANT]; k += 2) {
+            const char *prefix = tv->item[MCX_TS_VARIANT][k];
+            const size_t pl = strlen(prefix);
+            if (name.compare(0, pl, prefix) == 0) {
+                std::string second = (std::string(tv->item[MCX_TS_VARIANT][k + 1]) + name.substr(pl)).substr(0, 127);
+                if (second != first)
+                    by_name[second].push_back(v);
+                break; /* the first rule that fits, no other */
+            }
+        }
+    }
+    uint64_t total = 0;
+    mark_off[0] = 0;
+    for (uint32_t d = 0; d < D; ++d) {
+        auto it = by_name.find(std::string(drv_arena + drv_off[d], drv_off[d + 1] - drv_off[d]));
+        if (it != by_name.end())
+            for (uint32_t v : it->second) { /* pushed in ascending module order */
+                if (total < cap)
+                    mark_ids[total] = v;
+                ++total;
+            }
+        if (total > 0xFFFFFFFFull)
+            return MCX_E_TOO_LARGE;
+        mark_off[d + 1] = (uint32_t)total;
+    }
+    *total_out = total;
+    return total > cap ? MCX_E_TOO_LARGE : MCX_OK;
 }
 
 /* host: drv_mod[d] = id of the module whose name is byte for byte the d-th driver name

@@ -103,7 +103,8 @@ fl_scatter_used(const uint32_t *__restrict__ first_idx, const uint32_t *__restri
  * stores instead of one atomic per device on a row 4 * HW bytes from the next.
  * Dynamic LDS: V words, twice that with bound_mod (a column of U and one of L).
  */
-#define FL_COL_LDS_MAX 65536u
+#define FL_COL_LDS_MAX 65536u   /* what a block may ask for without raising the kernel's limit */
+#define FL_COL_LDS_STATIC 256u  /* the column kernels' own static part (hoff), rounded up */
 __global__ void __launch_bounds__(FL_THREADS)
 fl_scatter_cols(const uint32_t *__restrict__ first_idx, const uint32_t *__restrict__ a_mod,
                 const uint32_t *__restrict__ bound_mod, uint32_t N, const uint32_t *__restrict__ dev_off,
@@ -168,6 +169,90 @@ fl_scatter_extra(const uint32_t *__restrict__ extra_off, const uint32_t *__restr
     const uint32_t m = extra_ids[k];
     if (m < V)
         fl_set(L, HW, m, fl_owner(extra_off, H, k));
+}
+
+/*
+ * "(In Use)" labels (reference desktop/ui.py:1579-1590 asks mc_driver_is_in_use for every
+ * module it lists; montecarlo/libmontecarlo.c:573-725 answers from the device links under
+ * /sys/bus/{pci,usb,pcmcia}/drivers/<name> for the module's name and its name variant).
+ * Over records: every device of a host on one of those three buses - listed or not, inside
+ * the list's limit or beyond - that has a driver bound marks the modules that driver's name
+ * stands for (mark_off / mark_ids by driver number, mcx_driver_marks).  I[module][host], same
+ * layout as U and L.  By word column like fl_scatter_cols; fl_mark_rec is the one-thread-per-
+ * record form for module counts whose column does not fit LDS.
+ */
+__device__ __forceinline__ bool fl_bus_has_driver_links(uint32_t subsystem)
+{
+    return subsystem == MCX_SUB_PCI || subsystem == MCX_SUB_USB || subsystem == MCX_SUB_PCMCIA;
+}
+
+__global__ void __launch_bounds__(FL_THREADS)
+fl_mark_cols(const uint4 *__restrict__ rec, uint32_t N, const uint32_t *__restrict__ dev_off, uint32_t H,
+             const uint32_t *__restrict__ mark_off, const uint32_t *__restrict__ mark_ids, uint32_t D, uint32_t V,
+             uint32_t HW, uint32_t *__restrict__ I)
+{
+    extern __shared__ uint32_t fl_col[];
+    __shared__ uint32_t hoff[33];
+    const uint32_t w = blockIdx.x, h0 = 32u * w, nh = min(32u, H - h0);
+    if (threadIdx.x <= nh)
+        hoff[threadIdx.x] = dev_off[h0 + threadIdx.x];
+    for (uint32_t v = threadIdx.x; v < V; v += FL_THREADS)
+        fl_col[v] = 0u;
+    __syncthreads();
+    const uint32_t i0 = hoff[0], i1 = min(hoff[nh], N);
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += FL_THREADS) {
+        const uint4 r = rec[i]; /* mcx_dev_rec_t: subsystem in the low byte of x, driver number in w */
+        const uint32_t d = r.w;
+        if (!fl_bus_has_driver_links(r.x & 0xFFu) || d >= D)
+            continue;
+        const uint32_t e1 = mark_off[d + 1];
+        uint32_t e = mark_off[d];
+        if (e >= e1)
+            continue;
+        uint32_t lo = 0, hi = nh;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (hoff[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        for (; e < e1; ++e) {
+            const uint32_t m = mark_ids[e];
+            if (m < V)
+                atomicOr(&fl_col[m], 1u << lo);
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < V; v += FL_THREADS) {
+        const uint32_t u = fl_col[v];
+        if (u != 0u)
+            I[(size_t)v * HW + w] = u;
+    }
+}
+
+__global__ void __launch_bounds__(FL_THREADS)
+fl_mark_rec(const uint4 *__restrict__ rec, uint32_t N, const uint32_t *__restrict__ dev_off, uint32_t H,
+            const uint32_t *__restrict__ mark_off, const uint32_t *__restrict__ mark_ids, uint32_t D, uint32_t V,
+            uint32_t HW, uint32_t *I)
+{
+    const uint32_t i = blockIdx.x * FL_THREADS + threadIdx.x;
+    if (i >= N)
+        return;
+    const uint4 r = rec[i];
+    const uint32_t d = r.w;
+    if (!fl_bus_has_driver_links(r.x & 0xFFu) || d >= D)
+        return;
+    const uint32_t e1 = mark_off[d + 1];
+    uint32_t e = mark_off[d];
+    if (e >= e1)
+        return;
+    const uint32_t h = fl_owner(dev_off, H, i);
+    for (; e < e1; ++e) {
+        const uint32_t m = mark_ids[e];
+        if (m < V)
+            fl_set(I, HW, m, h);
+    }
 }
 
 /*
@@ -265,15 +350,16 @@ fl_level_sliced(const uint32_t *__restrict__ order, uint32_t n_rows, const uint3
  * seg.  fl_seg_prefix turns these into where each segment starts inside its
  * host's list and the host totals; after the scan of the totals FILL = true
  * writes the module ids from root_off[h] + seg_cnt[seg][h] on, so every host's
- * list comes out sorted.
+ * list comes out sorted.  LABEL: next to every id the "(In Use)" byte from the matrix I.
  */
 #define FLC_THREADS 64
 #define FLC_ROWS 32u
 #define FLC_SEGS 16u
-template <bool FILL>
+template <bool FILL, bool LABEL = false>
 __global__ void __launch_bounds__(FLC_THREADS)
 fl_columns(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, uint32_t *__restrict__ seg_cnt,
-           const uint32_t *__restrict__ root_off, uint32_t *__restrict__ root_ids)
+           const uint32_t *__restrict__ root_off, uint32_t *__restrict__ root_ids,
+           const uint32_t *__restrict__ I = nullptr, uint8_t *__restrict__ root_in_use = nullptr)
 {
     __shared__ uint32_t cur[32][FLC_THREADS];
     const uint32_t tid = threadIdx.x;
@@ -304,6 +390,8 @@ fl_columns(const uint32_t *__restrict__ R, uint32_t V, uint32_t H, uint32_t HW, 
                 const uint32_t at = cur[b][tid]++;
                 if (FILL)
                     root_ids[at] = v0 + k;
+                if (FILL && LABEL) /* one byte per entry: the host's bit of the module's row of I */
+                    root_in_use[at] = (uint8_t)((I[(size_t)(v0 + k) * HW + w] >> b) & 1u);
             }
         }
     }
@@ -340,14 +428,18 @@ fl_seg_prefix(uint32_t *__restrict__ seg_cnt, uint32_t H, uint32_t *__restrict__
 /* C ABI                                                                      */
 /* ------------------------------------------------------------------------- */
 
-extern "C" {
-
-/* d_bound_mod == nullptr: used = the modules the modaliases resolve to; otherwise used = d_bound_mod[i] */
-static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
-                               uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
-                               const void *d_safe_name, const void *d_bound_mod, void *d_root_off, void *d_root_ids,
-                               uint64_t cap, uint64_t *total_out)
+/* d_bound_mod == nullptr: used = the modules the modaliases resolve to; otherwise used = d_bound_mod[i].
+ * lab (may be nullptr): where the "(In Use)" byte of every listed module comes from and goes to. */
+int mcx_fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
+                            uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                            const void *d_safe_name, const void *d_bound_mod, const mcx_fleet_labels *lab,
+                            void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out)
 {
+    if (lab && !lab->root_in_use)
+        lab = nullptr;
+    if (lab && ((lab->Y && (!lab->inuse_off || !lab->inuse_ids)) ||
+                (lab->n_rec && (!lab->rec || !lab->rec_off)) || (lab->D && lab->n_rec && (!lab->mark_off || !lab->mark_ids))))
+        return MCX_E_BAD_ARG;
     if (!ctx || !d_s_off || !d_dev_off || !d_extra_off || !d_root_off || !total_out || (X && !d_extra_ids) ||
         (cap && !d_root_ids))
         return MCX_E_BAD_ARG;
@@ -394,13 +486,14 @@ static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_of
         if ((rc = mcx_alias_match_dev(ctx, d_S, d_s_off, N, d_first, d_count)) != MCX_OK)
             return rc;
         const size_t col_lds = 4 * (size_t)V * (d_bound_mod ? 2 : 1);
-        if (col_lds <= FL_COL_LDS_MAX)
+        if (col_lds + FL_COL_LDS_STATIC <= FL_COL_LDS_MAX)
             fl_scatter_cols<<<HW, FL_THREADS, col_lds, ctx->stream>>>(d_first, ctx->d_amod,
                                                                       (const uint32_t *)d_bound_mod, N,
                                                                       (const uint32_t *)d_dev_off, H, V, HW, U, L);
         else
             fl_scatter_used<<<(N + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
                 d_first, ctx->d_amod, (const uint32_t *)d_bound_mod, N, (const uint32_t *)d_dev_off, H, V, HW, U, L);
+        HIPCHK(ctx, hipGetLastError());
     }
     if (X)
         fl_scatter_extra<<<(X + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
@@ -433,6 +526,25 @@ static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_of
     fl_scan_top<<<1, FL_THREADS, 0, ctx->stream>>>(d_bsum, nb, d_total);
     fl_scan_apply<<<nb, FL_THREADS, 0, ctx->stream>>>(d_cnt, H, d_bsum, (uint32_t *)d_root_off);
     HIPCHK(ctx, hipGetLastError());
+    if (lab) {
+        /* the loaded sets are not needed any more: L becomes I, the hosts on which a bound
+         * device marks the module */
+        HIPCHK(ctx, hipMemsetAsync(L, 0, mat, ctx->stream));
+        if (lab->Y)
+            fl_scatter_extra<<<(lab->Y + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+                lab->inuse_off, lab->inuse_ids, lab->Y, H, V, HW, L);
+        if (lab->n_rec && lab->D) {
+            if (4 * (size_t)V + FL_COL_LDS_STATIC <= FL_COL_LDS_MAX)
+                fl_mark_cols<<<HW, FL_THREADS, 4 * (size_t)V, ctx->stream>>>((const uint4 *)lab->rec, lab->n_rec,
+                                                                           lab->rec_off, H, lab->mark_off,
+                                                                           lab->mark_ids, lab->D, V, HW, L);
+            else
+                fl_mark_rec<<<(lab->n_rec + FL_THREADS - 1) / FL_THREADS, FL_THREADS, 0, ctx->stream>>>(
+                    (const uint4 *)lab->rec, lab->n_rec, lab->rec_off, H, lab->mark_off, lab->mark_ids, lab->D, V, HW,
+                    L);
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
     unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
     HIPCHK(ctx, hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -445,7 +557,11 @@ static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_of
         ctx->err = "root_ids too small: " + std::to_string(*h_total) + " entries needed";
         return MCX_E_TOO_LARGE;
     }
-    if (*h_total)
+    if (*h_total && lab)
+        fl_columns<true, true><<<col_grid, FLC_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_seg,
+                                                                          (const uint32_t *)d_root_off,
+                                                                          (uint32_t *)d_root_ids, L, lab->root_in_use);
+    else if (*h_total)
         fl_columns<true><<<col_grid, FLC_THREADS, 0, ctx->stream>>>(U, V, H, HW, d_seg,
                                                                     (const uint32_t *)d_root_off,
                                                                     (uint32_t *)d_root_ids);
@@ -453,13 +569,15 @@ static int fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_of
     return MCX_OK;
 }
 
+extern "C" {
+
 int mcx_fleet_roots_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
                         uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
                         const void *d_safe_name, void *d_root_off, void *d_root_ids, uint64_t cap,
                         uint64_t *total_out)
 {
-    return fleet_roots_enqueue(ctx, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe_name, nullptr,
-                               d_root_off, d_root_ids, cap, total_out);
+    return mcx_fleet_roots_enqueue(ctx, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe_name,
+                                   nullptr, nullptr, d_root_off, d_root_ids, cap, total_out);
 }
 
 int mcx_fleet_roots_bound_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
@@ -469,17 +587,46 @@ int mcx_fleet_roots_bound_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off
 {
     if (N && !d_bound_mod)
         return MCX_E_BAD_ARG;
-    return fleet_roots_enqueue(ctx, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe_name,
-                               N ? d_bound_mod : nullptr, d_root_off, d_root_ids, cap, total_out);
+    return mcx_fleet_roots_enqueue(ctx, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe_name,
+                                   N ? d_bound_mod : nullptr, nullptr, d_root_off, d_root_ids, cap, total_out);
 }
 
+int mcx_fleet_roots_labeled_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N,
+                                const void *d_dev_off, uint32_t H, const void *d_extra_off, const void *d_extra_ids,
+                                uint32_t X, const void *d_safe_name, const void *d_bound_mod,
+                                const void *d_inuse_off, const void *d_inuse_ids, uint32_t Y, void *d_root_off,
+                                void *d_root_ids, void *d_root_in_use, uint64_t cap, uint64_t *total_out)
+{
+    if ((N && !d_bound_mod) || !d_inuse_off || (cap && !d_root_in_use))
+        return MCX_E_BAD_ARG;
+    mcx_fleet_labels lab;
+    lab.inuse_off = (const uint32_t *)d_inuse_off;
+    lab.inuse_ids = (const uint32_t *)d_inuse_ids;
+    lab.Y = Y;
+    lab.root_in_use = (uint8_t *)d_root_in_use;
+    return mcx_fleet_roots_enqueue(ctx, d_S, d_s_off, N, d_dev_off, H, d_extra_off, d_extra_ids, X, d_safe_name,
+                                   N ? d_bound_mod : nullptr, &lab, d_root_off, d_root_ids, cap, total_out);
+}
+
+/* inuse_off != nullptr: with "(In Use)" labels from the hosts' lists of marked modules */
 static int fleet_roots_host(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
                             uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids,
-                            const uint8_t *safe_name, const uint32_t *bound_mod, bool with_bound, uint32_t *root_off,
-                            uint32_t *root_ids, uint64_t cap, uint64_t *total_out)
+                            const uint8_t *safe_name, const uint32_t *bound_mod, bool with_bound,
+                            const uint32_t *inuse_off, const uint32_t *inuse_ids, uint32_t *root_off,
+                            uint32_t *root_ids, uint8_t *root_in_use, uint64_t cap, uint64_t *total_out)
 {
     if (!ctx || !s_off || !dev_off || !extra_off || !root_off || !total_out || (with_bound && N && !bound_mod))
         return MCX_E_BAD_ARG;
+    const uint32_t Y = inuse_off ? inuse_off[H] : 0u;
+    if (inuse_off) {
+        if (inuse_off[0] != 0 || (Y && !inuse_ids) || (cap && !root_in_use))
+            return MCX_E_BAD_ARG;
+        for (uint32_t h = 0; h < H; ++h)
+            if (inuse_off[h + 1] < inuse_off[h]) {
+                ctx->err = "host offsets not monotonic";
+                return MCX_E_BAD_ARG;
+            }
+    }
     if (!ctx->table_loaded || !ctx->graph_loaded)
         return MCX_E_NOT_LOADED;
     if (dev_off[0] != 0 || dev_off[H] != N || extra_off[0] != 0) {
@@ -509,7 +656,9 @@ static int fleet_roots_host(mcx_ctx *ctx, const char *S, const uint32_t *s_off, 
     const size_t o_safe = o_xid + up256(4 * (size_t)(X ? X : 1)), o_roff = o_safe + up256(V ? V : 1);
     const size_t o_rid = o_roff + up256(4 * ((size_t)H + 1));
     const size_t o_bound = o_rid + up256(4 * (size_t)(cap ? cap : 1));
-    const size_t bytes = o_bound + up256(4 * (size_t)(N ? N : 1));
+    const size_t o_yoff = o_bound + up256(4 * (size_t)(N ? N : 1)), o_yid = o_yoff + up256(4 * ((size_t)H + 1));
+    const size_t o_use = o_yid + up256(4 * (size_t)(Y ? Y : 1));
+    const size_t bytes = o_use + up256(cap ? cap : 1);
     char *d = nullptr;
     if (hipMalloc((void **)&d, bytes) != hipSuccess) {
         ctx->err = "hipMalloc of the staging buffers failed";
@@ -530,21 +679,34 @@ static int fleet_roots_host(mcx_ctx *ctx, const char *S, const uint32_t *s_off, 
         e = hipMemcpyAsync(d + o_safe, safe_name, V, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && with_bound && N)
         e = hipMemcpyAsync(d + o_bound, bound_mod, 4 * (size_t)N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && inuse_off)
+        e = hipMemcpyAsync(d + o_yoff, inuse_off, 4 * ((size_t)H + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && Y)
+        e = hipMemcpyAsync(d + o_yid, inuse_ids, 4 * (size_t)Y, hipMemcpyHostToDevice, ctx->stream);
+    mcx_fleet_labels lab;
+    if (inuse_off) {
+        lab.inuse_off = (const uint32_t *)(d + o_yoff);
+        lab.inuse_ids = (const uint32_t *)(d + o_yid);
+        lab.Y = Y;
+        lab.root_in_use = (uint8_t *)(d + o_use);
+    }
     int rc = MCX_OK;
     if (e != hipSuccess) {
         ctx->err = std::string("copy in: ") + hipGetErrorString(e);
         rc = MCX_E_HIP;
     }
     if (rc == MCX_OK)
-        rc = fleet_roots_enqueue(ctx, d, d + o_soff, N, d + o_dev, H, d + o_xoff, d + o_xid, X, d + o_safe,
-                                 with_bound && N ? d + o_bound : nullptr, d + o_roff, cap ? d + o_rid : nullptr, cap,
-                                 total_out);
+        rc = mcx_fleet_roots_enqueue(ctx, d, d + o_soff, N, d + o_dev, H, d + o_xoff, d + o_xid, X, d + o_safe,
+                                     with_bound && N ? d + o_bound : nullptr, inuse_off && cap ? &lab : nullptr,
+                                     d + o_roff, cap ? d + o_rid : nullptr, cap, total_out);
     /* the offsets are valid even when root_ids was too small: a caller may
      * size the list from them and call again */
     if (rc == MCX_OK || (rc == MCX_E_TOO_LARGE && *total_out <= 0xFFFFFFFFull && *total_out > cap)) {
         e = hipMemcpyAsync(root_off, d + o_roff, 4 * ((size_t)H + 1), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && rc == MCX_OK && *total_out)
             e = hipMemcpyAsync(root_ids, d + o_rid, 4 * (size_t)*total_out, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == MCX_OK && *total_out && inuse_off)
+            e = hipMemcpyAsync(root_in_use, d + o_use, (size_t)*total_out, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess)
             e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -561,8 +723,8 @@ int mcx_fleet_roots(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
                     uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids, const uint8_t *safe_name,
                     uint32_t *root_off, uint32_t *root_ids, uint64_t cap, uint64_t *total_out)
 {
-    return fleet_roots_host(ctx, S, s_off, N, dev_off, H, extra_off, extra_ids, safe_name, nullptr, false, root_off,
-                            root_ids, cap, total_out);
+    return fleet_roots_host(ctx, S, s_off, N, dev_off, H, extra_off, extra_ids, safe_name, nullptr, false, nullptr,
+                            nullptr, root_off, root_ids, nullptr, cap, total_out);
 }
 
 int mcx_fleet_roots_bound(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
@@ -570,8 +732,20 @@ int mcx_fleet_roots_bound(mcx_ctx *ctx, const char *S, const uint32_t *s_off, ui
                           const uint32_t *bound_mod, uint32_t *root_off, uint32_t *root_ids, uint64_t cap,
                           uint64_t *total_out)
 {
-    return fleet_roots_host(ctx, S, s_off, N, dev_off, H, extra_off, extra_ids, safe_name, bound_mod, true, root_off,
-                            root_ids, cap, total_out);
+    return fleet_roots_host(ctx, S, s_off, N, dev_off, H, extra_off, extra_ids, safe_name, bound_mod, true, nullptr,
+                            nullptr, root_off, root_ids, nullptr, cap, total_out);
+}
+
+int mcx_fleet_roots_labeled(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, const uint32_t *dev_off,
+                            uint32_t H, const uint32_t *extra_off, const uint32_t *extra_ids, const uint8_t *safe_name,
+                            const uint32_t *bound_mod, const uint32_t *inuse_off, const uint32_t *inuse_ids,
+                            uint32_t *root_off, uint32_t *root_ids, uint8_t *root_in_use, uint64_t cap,
+                            uint64_t *total_out)
+{
+    if (!inuse_off)
+        return MCX_E_BAD_ARG;
+    return fleet_roots_host(ctx, S, s_off, N, dev_off, H, extra_off, extra_ids, safe_name, bound_mod, true, inuse_off,
+                            inuse_ids, root_off, root_ids, root_in_use, cap, total_out);
 }
 
 } /* extern "C" */

@@ -239,6 +239,26 @@ static int mcx_dev_upload(mcx_ctx *ctx, T **d_out, const T *src, size_t count)
 void mcx_free_table(mcx_ctx *ctx);
 /* d_hw[m] = 1 iff module m < n_modules owns a hardware-bus alias; enqueues */
 int mcx_k1_hw_flags_dev(mcx_ctx *ctx, uint32_t n_modules, uint8_t *d_hw);
+
+/* Where the "(In Use)" byte of every listed module comes from (device pointers): per-host
+ * lists of marked modules (inuse_off has H + 1 entries), and / or the records of all the
+ * hosts' devices (rec_off: H + 1 offsets into rec) with the driver-number -> modules map of
+ * mcx_driver_marks; root_in_use receives one byte per entry of root_ids. */
+struct mcx_fleet_labels {
+    const uint32_t *inuse_off = nullptr, *inuse_ids = nullptr;
+    uint32_t Y = 0;
+    const mcx_dev_rec_t *rec = nullptr;
+    const uint32_t *rec_off = nullptr;
+    uint32_t n_rec = 0;
+    const uint32_t *mark_off = nullptr, *mark_ids = nullptr;
+    uint32_t D = 0;
+    uint8_t *root_in_use = nullptr;
+};
+/* the fleet pipeline behind every mcx_fleet_roots* entry point (mcx_fleet.hip) */
+int mcx_fleet_roots_enqueue(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint32_t N, const void *d_dev_off,
+                            uint32_t H, const void *d_extra_off, const void *d_extra_ids, uint32_t X,
+                            const void *d_safe_name, const void *d_bound_mod, const mcx_fleet_labels *lab,
+                            void *d_root_off, void *d_root_ids, uint64_t cap, uint64_t *total_out);
 void mcx_free_graph(mcx_ctx *ctx);
 /* device address of the static bitmap of mcx_dep_flags_noalloc_dev on the context's
  * device (which must be current); called once per context at creation */

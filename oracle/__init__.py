@@ -53,6 +53,8 @@ def oracle():
         lib.orc_fleet_roots_bound.argtypes = [_vp, _vp, u32, _vp, _vp, _vp, u32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.orc_alias_match_list.restype = u64
         lib.orc_alias_match_list.argtypes = [_vp, _vp, u32, _vp, _vp, u32, ctypes.c_int, u32, _vp, _vp]
+        lib.orc_fleet_in_use.restype = None
+        lib.orc_fleet_in_use.argtypes = [_vp, _vp, u32, _vp, _vp, _vp, _vp, u32, _vp, _vp, u32, _vp]
         lib.orc_device_filter.restype = None
         lib.orc_device_filter.argtypes = [_vp, u32, _vp, _vp, u32, _vp, u32, u32, _vp, _vp]
         _ORC = lib
@@ -261,6 +263,24 @@ def fleet_roots(rowptr, col, driver_mod, dev_off, extra_off, extra_ids, safe_nam
     ids = np.zeros(max(total, 1), dtype=np.uint32)
     fn(*args, _p(ids))
     return root_off, ids[:total]
+
+
+def fleet_in_use(root_off, root_ids, rec, rec_off, drv_arena, drv_off, mod_arena, mod_off):
+    """the "(In Use)" byte of every listed module: mc_driver_is_in_use restated over the hosts'
+    device records (all of them, listed or not), driver names and module names packed"""
+    root_off = np.ascontiguousarray(root_off, dtype=np.uint32)
+    root_ids = _c(root_ids, np.uint32)
+    rec_off = np.ascontiguousarray(rec_off, dtype=np.uint32)
+    drv_off = np.ascontiguousarray(drv_off, dtype=np.uint32)
+    mod_off = np.ascontiguousarray(mod_off, dtype=np.uint32)
+    H = len(root_off) - 1
+    n = int(root_off[H])
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    recb = np.ascontiguousarray(rec).view(np.uint8) if len(rec) else np.zeros(16, np.uint8)
+    oracle().orc_fleet_in_use(_p(root_off), _p(root_ids), H, _p(recb), _p(rec_off), _p(_c(drv_arena, np.uint8)),
+                              _p(drv_off), len(drv_off) - 1, _p(_c(mod_arena, np.uint8)), _p(mod_off),
+                              len(mod_off) - 1, _p(out))
+    return out[:n]
 
 
 def device_filter(rec, drv_arena, drv_off, dev_off, max_per_host=0):

@@ -517,6 +517,73 @@ uint64_t orc_fleet_roots_bound(const uint32_t *rowptr, const uint32_t *col, uint
                             hw_alias, root_off, root_ids);
 }
 
+/* ---- "(In Use)" / "(Idle)" of the dashboard's module rows ---------------------
+ * reference desktop/ui.py:1579-1590: for every module it lists the dashboard asks
+ * mc_driver_is_in_use(mod).  Restated from montecarlo/libmontecarlo.c:538-566
+ * (get_driver_names) and :573-725 over records instead of sysfs: the directory
+ * /sys/bus/<bus>/drivers/<name> holds a device link exactly when some device of the host
+ * sits on <bus> with <name> bound, whatever the device list makes of that device.  The
+ * holders part (:699-722) cannot fire for a listed module (ui.py:1575-1577 dropped those).
+ */
+static int orc_names_of_module(const char *module_name, char names[][128], int max_names)
+{
+    int count = 0;
+    if (!module_name || count >= max_names)
+        return 0;
+    strncpy(names[count], module_name, 127); /* :548-550 */
+    names[count][127] = 0;
+    count++;
+    if (strncmp(module_name, "rtw88_", 6) == 0 && count < max_names) { /* :553-559 */
+        snprintf(names[count], 128, "rtw_%s", module_name + 6);
+        count++;
+    } else if (strncmp(module_name, "rtl", 3) == 0 && count < max_names) { /* :560-565 */
+        snprintf(names[count], 128, "rtw_%s", module_name + 3);
+        count++;
+    }
+    return count;
+}
+
+/* rec: all the hosts' device records (16 bytes each, layout of mcx_dev_rec_t: subsystem in
+ * byte 0, driver number in bytes 12..15), host h owns rec_off[h] .. rec_off[h+1]; driver and
+ * module names packed with offsets; in_use[k] for k < root_off[H]. */
+void orc_fleet_in_use(const uint32_t *root_off, const uint32_t *root_ids, uint32_t H, const uint8_t *rec,
+                      const uint32_t *rec_off, const char *drv_arena, const uint32_t *drv_off, uint32_t D,
+                      const char *mod_names, const uint32_t *mod_off, uint32_t V, uint8_t *in_use)
+{
+    static const uint8_t buses[3] = {1 /* pci, :590-624 */, 0 /* usb, :626-660 */, 4 /* pcmcia, :662-696 */};
+    for (uint32_t h = 0; h < H; ++h)
+        for (uint32_t k = root_off[h]; k < root_off[h + 1]; ++k) {
+            const uint32_t m = root_ids[k];
+            in_use[k] = 0;
+            if (m >= V)
+                continue;
+            char mod[256];
+            size_t ml = mod_off[m + 1] - mod_off[m];
+            if (ml > 255)
+                ml = 255;
+            memcpy(mod, mod_names + mod_off[m], ml);
+            mod[ml] = 0;
+            if (mod[0] == 0) /* :575-578 */
+                continue;
+            char names[4][128];
+            const int n_names = orc_names_of_module(mod, names, 4);
+            for (int n = 0; n < n_names && !in_use[k]; ++n)
+                for (int b = 0; b < 3 && !in_use[k]; ++b)
+                    for (uint32_t i = rec_off[h]; i < rec_off[h + 1]; ++i) {
+                        const uint8_t *r = rec + 16 * (size_t)i;
+                        uint32_t d;
+                        memcpy(&d, r + 12, 4);
+                        if (r[0] != buses[b] || d >= D)
+                            continue;
+                        const size_t dl = drv_off[d + 1] - drv_off[d];
+                        if (dl == strlen(names[n]) && memcmp(drv_arena + drv_off[d], names[n], dl) == 0) {
+                            in_use[k] = 1;
+                            break;
+                        }
+                    }
+        }
+}
+
 /*
  * All matching table positions per string, in table order (what kmod's
  * `modprobe -R` prints module by module), the first K of them when K > 0.

@@ -134,3 +134,37 @@ def test_oracle_bound_mode_by_hand(oracle_mod):
     off, ids = oracle_mod.fleet_roots(rowptr, col, resolved, dev_off, extra_off, np.zeros(0, np.uint32), ones, ones,
                                       bound_mod=bound)
     assert off.tolist() == [0, 1] and ids.tolist() == [2]
+
+
+def test_driver_marks_by_hand():
+    """driver name -> the modules it marks "(In Use)": the module of that name and the modules
+    whose name variant it is (reference montecarlo/libmontecarlo.c:552-565: rtw88_X -> rtw_X,
+    else rtlX -> rtw_X; only the first rule that fits; a nameless module marks nothing)"""
+    from montecarlo_amd import driver_marks
+
+    mods = ["rtw88_8821cu", "rtl8821cu", "rtw_8821cu", "e1000", "rtlwifi", "", "e1000", "rtw88_"]
+    drv = ["rtw_8821cu", "rtw88_8821cu", "e1000", "rtw_wifi", "rtw_", "", "rtl8821cu", "nope"]
+    off, ids = driver_marks(drv, mods)
+    got = [ids[off[d]:off[d + 1]].tolist() for d in range(len(drv))]
+    assert got == [[0, 1, 2], [0], [3, 6], [4], [7], [], [1], []]
+    off, ids = driver_marks([], mods)
+    assert off.tolist() == [0] and len(ids) == 0
+    off, ids = driver_marks(drv, [])
+    assert off.tolist() == [0] * (len(drv) + 1)
+    # names are cut at 127 bytes, as the reference's buffers cut them
+    long = "x" * 200
+    off, ids = driver_marks([long[:127], long, "rtw_" + "y" * 123], [long, "rtl" + "y" * 150])
+    assert [ids[off[d]:off[d + 1]].tolist() for d in range(3)] == [[0], [], [1]]
+
+
+def test_oracle_in_use_labels_by_hand(oracle_mod):
+    """the oracle's restatement of mc_driver_is_in_use on the hand-worked host: variant names,
+    a dashed driver name, a driver bound only to a bridge / to a device behind the list's limit /
+    only on the hid bus"""
+    from fleet_cases import HAND_LIMIT, HAND_LISTED, HAND_WANT, hand_case, labeled_expectation
+
+    f, rec, table, names = hand_case()
+    e = labeled_expectation(oracle_mod, f, rec, table, names, HAND_LIMIT)
+    assert [int(x) for x in (e["o_v"] & 1)] == HAND_LISTED
+    got = {names[int(m)]: int(u) for m, u in zip(e["w_ids"], e["w_use"])}
+    assert got == HAND_WANT

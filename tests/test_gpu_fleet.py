@@ -7,6 +7,8 @@ import pytest
 from montecarlo_amd import McxError, safe_module_names, synth
 from montecarlo_amd.binding import pack_strings
 
+from fleet_cases import HAND_LIMIT, HAND_LISTED, HAND_WANT, hand_case, inuse_lists, labeled_expectation, variant
+
 pytestmark = pytest.mark.gpu
 NO_MATCH = 0xFFFFFFFF
 
@@ -58,11 +60,12 @@ def test_fleet_vs_oracle(gpu_ctx, oracle_mod, seed, P, H, mean_dev, max_extra):
     assert len(ids) > 0 or H == 1
 
 
-@pytest.mark.parametrize("V", [10000, 20000])
+@pytest.mark.parametrize("V", [8128, 8192, 10000, 16320, 16384, 20000])
 def test_fleet_many_modules(gpu_ctx, oracle_mod, V):
     """module counts around the sizes at which the used-driver bits stop being built by word
-    column in LDS (one column of V words, two with bound drivers: 64 KB) and go back to one
-    atomic per device: both modes against the oracle on either side"""
+    column in LDS (one column of V words, two with bound drivers: 64 KB together with the
+    kernel's own 256 bytes) and go back to one atomic per device: both modes against the oracle
+    on either side of both limits and right at them"""
     f = make_fleet(91, 3000, 300, 10, 6, V=V)
     assert f["V"] == V and int(f["extra_ids"].max()) > synth.alias_modules(3000)
     off, ids = run_fleet(gpu_ctx, f)
@@ -330,3 +333,97 @@ def test_inventory_with_bound_drivers(gpu_ctx, oracle_mod):
         assert np.array_equal(d_rid.download(np.uint32, total), w_ids)
     for buf in bufs + [d_v, d_roff, d_rid]:
         buf.free()
+
+
+# ---- "(In Use)" / "(Idle)" labels ---------------------------------------------------------
+
+def _run_inventory_labeled(ctx, f, rec, e, table, names, max_per_host):
+    from montecarlo_amd import driver_marks
+    mark_off, mark_ids = driver_marks(table, names)
+    N, H = f["N"], f["H"]
+    bufs = [ctx.to_device(x) for x in (rec, f["S"], f["s_off"], e["arena"], e["off"], e["drv_mod"], mark_off,
+                                       mark_ids if len(mark_ids) else np.zeros(1, np.uint32), f["dev_off"],
+                                       f["extra_off"], f["extra_ids"], f["safe"])]
+    d_rec, d_S, d_soff, d_arena, d_doff, d_dm, d_moff, d_mid, d_dev, d_xoff, d_xid, d_safe = bufs
+    d_v, d_roff = ctx.alloc(max(N, 1)), ctx.alloc(4 * (H + 1))
+    args = (d_rec.ptr, d_S.ptr, d_soff.ptr, N, d_arena.ptr, d_doff.ptr, len(table), d_dm.ptr, d_moff.ptr, d_mid.ptr,
+            d_dev.ptr, H, max_per_host, d_xoff.ptr, d_xid.ptr, len(f["extra_ids"]), d_safe.ptr, d_v.ptr, d_roff.ptr)
+    total = ctx.fleet_inventory_roots_labeled_dev(*args, None, None, 0, size_only=True)
+    d_rid, d_use = ctx.alloc(4 * max(total, 1)), ctx.alloc(max(total, 1))
+    assert ctx.fleet_inventory_roots_labeled_dev(*args, d_rid.ptr, d_use.ptr, total) == total
+    out = (d_roff.download(np.uint32, H + 1), d_rid.download(np.uint32, total), d_use.download(np.uint8, total),
+           d_v.download(np.uint8, N))
+    for buf in bufs + [d_v, d_roff, d_rid, d_use]:
+        buf.free()
+    return out, (mark_off, mark_ids)
+
+
+def test_in_use_label_hand_case(gpu_ctx, oracle_mod):
+    """the hand-worked host of tests/fleet_cases.py::hand_case: the library's labels are the
+    documented ones and the oracle's"""
+    f, rec, table, names = hand_case()
+    gpu_ctx.alias_table_load(f["A"], f["a_off"], f["a_mod"])
+    gpu_ctx.dep_graph_load(f["rowptr"], f["col"])
+    e = labeled_expectation(oracle_mod, f, rec, table, names, HAND_LIMIT)
+    (off, ids, use, verdict), _ = _run_inventory_labeled(gpu_ctx, f, rec, e, table, names, HAND_LIMIT)
+    assert np.array_equal(verdict & 3, e["o_v"])
+    assert [int(x) for x in (verdict & 1)] == HAND_LISTED
+    got = {names[int(m)]: int(u) for m, u in zip(ids, use)}
+    assert got == HAND_WANT
+    assert np.array_equal(off, e["w_off"]) and np.array_equal(ids, e["w_ids"]) and np.array_equal(use, e["w_use"])
+
+
+@pytest.mark.parametrize("seed,P,H,mean_dev,max_per_host,V", [(101, 3000, 300, 14, 0, None), (102, 2000, 130, 30, 8, None),
+                                                              (103, 3000, 200, 10, 0, 20000)])
+def test_in_use_labels_of_a_seeded_fleet(gpu_ctx, oracle_mod, seed, P, H, mean_dev, max_per_host, V):
+    """records -> device list -> module lists -> labels in one call, and the same through the
+    entry point that takes per-host lists of marked modules, both against the oracle's restatement
+    of mc_driver_is_in_use over the unfiltered records.  Drivers are bound under the module's own
+    name, its rtw88 / rtl variant, a dashed spelling, another module's name, or not at all; the
+    device filter hides about a fifth of the devices, whose bindings still count."""
+    from montecarlo_amd import driver_marks
+
+    f = make_fleet(seed, P, H, mean_dev, 4, V=V)
+    ctx, N, Vn = gpu_ctx, f["N"], f["V"]
+    names = synth.module_names(seed + 4, Vn)
+    rec = synth.device_records(seed, f["S"], f["s_off"])
+    variants = sorted({variant(n) for n in names if variant(n)})
+    table = list(synth.DRIVER_NAMES) + names[:600] + variants[:200] + [n.replace("_", "-") for n in names[600:650]]
+    at = {n: k for k, n in enumerate(table)}
+    first, _ = oracle_mod.alias_match(f["A"], f["a_off"], f["S"], f["s_off"], use_twin=True)
+    resolved = np.where(first != NO_MATCH, f["a_mod"][np.minimum(first, len(f["a_mod"]) - 1)], NO_MATCH)
+    rng = np.random.default_rng(seed)
+    drv = rec["driver"].copy()
+    for i in range(N):
+        m, r = int(resolved[i]), rng.random()
+        if m == NO_MATCH or r < 0.25:
+            continue                                   # what the generator drew (infra names, none, ...)
+        name = names[m]
+        if r < 0.55 and name in at:
+            drv[i] = at[name]
+        elif r < 0.75 and variant(name) in at:
+            drv[i] = at[variant(name)]
+        elif r < 0.85:
+            drv[i] = rng.integers(len(synth.DRIVER_NAMES), len(table))
+    rec["driver"] = drv
+    ctx.alias_table_load(f["A"], f["a_off"], f["a_mod"])
+    ctx.dep_graph_load(f["rowptr"], f["col"])
+    e = labeled_expectation(oracle_mod, f, rec, table, names, max_per_host)
+    (off, ids, use, verdict), (mark_off, mark_ids) = _run_inventory_labeled(ctx, f, rec, e, table, names, max_per_host)
+    assert np.array_equal(verdict & 3, e["o_v"])
+    assert np.array_equal(off, e["w_off"]) and np.array_equal(ids, e["w_ids"])
+    assert np.array_equal(use, e["w_use"])
+    assert 0 < int(use.sum()) < len(use)
+    # the marks by hand: name or variant, nothing else
+    for d in rng.integers(0, len(table), size=60):
+        want = [v for v, n in enumerate(names) if n == table[d] or variant(n) == table[d]]
+        assert mark_ids[mark_off[d]:mark_off[d + 1]].tolist() == want
+    # the other entry point: listed devices' strings + per-host lists of marked modules, host buffers
+    i_off, i_ids = inuse_lists(rec, f["dev_off"], mark_off, mark_ids, len(table))
+    off2, ids2, use2 = ctx.fleet_roots_labeled(e["Sk"], e["sk_off"], e["o_kept"], f["extra_off"], f["extra_ids"],
+                                               f["safe"], e["bound"], i_off, i_ids)
+    assert np.array_equal(off2, e["w_off"]) and np.array_equal(ids2, e["w_ids"]) and np.array_equal(use2, e["w_use"])
+    # and without labels nothing else changes
+    off3, ids3 = ctx.fleet_roots_bound(e["Sk"], e["sk_off"], e["o_kept"], f["extra_off"], f["extra_ids"], f["safe"],
+                                       e["bound"])
+    assert np.array_equal(off3, e["w_off"]) and np.array_equal(ids3, e["w_ids"])
