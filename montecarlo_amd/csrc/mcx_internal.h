@@ -138,8 +138,23 @@ static inline int mcx_scratch(mcx_ctx *ctx, size_t bytes, void **out)
     return MCX_OK;
 }
 
-/* word of h_pinned that a read-back kernel stores last (a value that grows with every use) */
+/*
+ * The 64 words of h_pinned, by user:
+ *   0 .. 35   closure search: sizes of a batch of levels, edge count, levels handed over
+ *             (mcx_k2.hip); the fleet calls and the device filter: a 64-bit total in 0..1
+ *   40        sequence word: what a read-back kernel stores last (grows with every use)
+ *   44 .. 49  the closure's early report (a one-workgroup launch that ended the search)
+ *   52 .. 55  the match lists' report: total and overflow count, each marked with the call's
+ *             number (mcx_k1.hip)
+ * A closure call may return on the early report while the rest of its batch is still queued:
+ * those launches find the search over, write zeros into 0..35 and the batch's number into 40
+ * after the call has returned.  They are stream-ordered in front of every later kernel, and
+ * host code trusts a word only for its mark (a sequence number it waits for, or a total a
+ * stream synchronisation stands behind), never for being unchanged since it last looked;
+ * the protocols that spin on marks of their own have words of their own.
+ */
 #define MCX_PINNED_SEQ_WORD 40u
+#define MCX_PINNED_LIST_WORD 52u
 
 /* the next value of the sequence word (never 0: kernels take 0 as "do not report") */
 static inline uint32_t mcx_next_seq(mcx_ctx *ctx)

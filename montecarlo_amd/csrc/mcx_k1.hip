@@ -2289,7 +2289,7 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
  * synchronise the stream instead, which also reports a failed launch. */
 static int k1_wait_report(mcx_ctx *ctx, uint32_t seq, unsigned long long *total, uint32_t *overflows)
 {
-    volatile unsigned long long *h = (volatile unsigned long long *)ctx->h_pinned;
+    volatile unsigned long long *h = (volatile unsigned long long *)(ctx->h_pinned + MCX_PINNED_LIST_WORD);
     const unsigned long long most = (1ull << K1_REPORT_BITS) - 1ull;
     const auto t0 = std::chrono::steady_clock::now();
     bool synced = false;
@@ -2365,7 +2365,7 @@ int mcx_alias_match_list_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off,
     uint32_t *d_tover = (uint32_t *)((char *)base + o_tover);
     unsigned long long *d_toff = (unsigned long long *)((char *)base + o_toff);
     uint2 *d_texts = (uint2 *)((char *)base + o_texts);
-    unsigned long long *h_total = (unsigned long long *)ctx->h_pinned;
+    unsigned long long *h_total = (unsigned long long *)(ctx->h_pinned + MCX_PINNED_LIST_WORD);
     k1_list_t L{nullptr, nullptr, ctx->d_dup_start, ctx->d_dup_idx, d_ns, d_texts, d_tsum, d_tover, K};
     /* one pass: counts, first matches, the short lists and what every tile's lists hold together;
      * then one launch that places the lists and writes them.  It does so before the host has seen

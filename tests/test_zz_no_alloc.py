@@ -72,3 +72,74 @@ def test_noalloc_refuses_graphs_beyond_the_static_bitmap(gpu_ctx):
     assert e.value.rc == -6
     d_in.free()
     d_out.free()
+
+
+def _hip():
+    """the HIP runtime the library itself is linked to, for the two things the test needs to
+    see from outside: free device memory and stream capture"""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    hip.hipMemGetInfo.argtypes = [ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    hip.hipStreamBeginCapture.argtypes = [vp, ctypes.c_int]
+    hip.hipStreamEndCapture.argtypes = [vp, ctypes.POINTER(vp)]
+    hip.hipGraphInstantiate.argtypes = [ctypes.POINTER(vp), vp, vp, vp, sz]
+    hip.hipGraphLaunch.argtypes = [vp, vp]
+    hip.hipGraphExecDestroy.argtypes = [vp]
+    hip.hipGraphDestroy.argtypes = [vp]
+    return hip
+
+
+def test_noalloc_allocates_nothing_and_can_be_captured(gpu_ctx):
+    """What the entry point is for: (1) free device memory is the same before and after a run
+    of calls; (2) the call is legal between hipStreamBeginCapture and hipStreamEndCapture on
+    the context's stream - where an allocation, a free or a synchronisation would end the
+    capture with an error - and the captured graph, launched, gives mcx_dep_flags_dev's
+    results."""
+    import ctypes
+
+    from montecarlo_amd import synth
+
+    hip = _hip()
+    V = 120_001
+    rowptr, col = synth.dep_graph(14, V, 7)
+    flags = synth.dep_flags(14, rowptr, col)
+    gpu_ctx.dep_graph_load(rowptr, col)
+    d_in = gpu_ctx.to_device(flags)
+    d_out, d_ref, d_want, d_wref = gpu_ctx.alloc(V), gpu_ctx.alloc(4 * V), gpu_ctx.alloc(V), gpu_ctx.alloc(4 * V)
+    gpu_ctx.dep_flags_dev(d_in.ptr, d_want.ptr, d_wref.ptr)
+    gpu_ctx.dep_flags_noalloc_dev(d_in.ptr, d_out.ptr, d_ref.ptr)   # first call: whatever is set up lazily
+    gpu_ctx.sync()
+    free0, free1, total = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total)) == 0
+    for _ in range(50):
+        gpu_ctx.dep_flags_noalloc_dev(d_in.ptr, d_out.ptr, d_ref.ptr)
+    gpu_ctx.sync()
+    assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total)) == 0
+    assert free1.value == free0.value, "the call changed the amount of free device memory"
+    # under capture
+    stream = gpu_ctx.lib.mcx_ctx_stream(gpu_ctx.h)
+    zeros = np.zeros(4 * V, dtype=np.uint8)
+    d_out.upload(zeros[:V])
+    d_ref.upload(zeros)
+    gpu_ctx.sync()
+    graph, graph_exec = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, 0) == 0          # hipStreamCaptureModeGlobal
+    try:
+        gpu_ctx.dep_flags_noalloc_dev(d_in.ptr, d_out.ptr, d_ref.ptr)
+    finally:
+        rc_end = hip.hipStreamEndCapture(stream, ctypes.byref(graph))
+    assert rc_end == 0 and graph.value, f"capture ended with HIP error {rc_end}"
+    # nothing ran yet: the outputs are still zero
+    gpu_ctx.sync()
+    assert not d_out.download(np.uint8, V).any()
+    assert hip.hipGraphInstantiate(ctypes.byref(graph_exec), graph, None, None, 0) == 0
+    for _ in range(2):
+        assert hip.hipGraphLaunch(graph_exec, stream) == 0
+    gpu_ctx.sync()
+    assert np.array_equal(d_out.download(np.uint8, V), d_want.download(np.uint8, V))
+    assert np.array_equal(d_ref.download(np.uint32, V), d_wref.download(np.uint32, V))
+    assert hip.hipGraphExecDestroy(graph_exec) == 0 and hip.hipGraphDestroy(graph) == 0
+    for b in (d_in, d_out, d_ref, d_want, d_wref):
+        b.free()
