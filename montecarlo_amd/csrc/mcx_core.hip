@@ -120,11 +120,11 @@ int mcx_ctx_create(int device_ordinal, void *stream, mcx_ctx **out)
         ctx->own_stream = true;
     }
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_pinned, 256, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_pinned, 4 * MCX_PINNED_WORDS, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         mcx_ctx_destroy(ctx);
         return MCX_E_NO_DEVICE;
     }
-    memset(ctx->h_pinned, 0, 256);
+    memset(ctx->h_pinned, 0, 4 * MCX_PINNED_WORDS);
     if (mcx_k2_static_init(ctx) != MCX_OK) {
         mcx_ctx_destroy(ctx);
         return MCX_E_NO_DEVICE;

@@ -75,8 +75,10 @@ struct mcx_ctx {
     bool bfs_clean = false;        /* the counters are zero (the last search ended and cleared them) */
     uint32_t n_hub[2] = {0, 0};    /* modules with a long adjacency list, per closure direction */
     uint32_t hub_cap = 0;
-    uint32_t *h_pinned = nullptr;  /* 256 bytes of pinned host memory for small read-backs */
+    uint32_t *h_pinned = nullptr;  /* MCX_PINNED_WORDS words of pinned host memory for small read-backs */
     uint32_t pinned_seq = 0;       /* last value a kernel was asked to leave in h_pinned[MCX_PINNED_SEQ_WORD] */
+    std::vector<uint32_t> bfs_sizes[2]; /* per direction: the frontier sizes of the last closure's per-level
+                                           launches (0xFFFFFFFF: a level with hubs) */
     uint32_t bfs_depth[2] = {0, 0}; /* per-level launches the last closure needed per direction behind its
                                        one-workgroup part (0: none, or no search yet) */
 
@@ -139,13 +141,14 @@ static inline int mcx_scratch(mcx_ctx *ctx, size_t bytes, void **out)
 }
 
 /*
- * The 64 words of h_pinned, by user:
+ * The words of h_pinned (MCX_PINNED_WORDS of them), by user:
  *   0 .. 35   closure search: sizes of a batch of levels, edge count, levels handed over
  *             (mcx_k2.hip); the fleet calls and the device filter: a 64-bit total in 0..1
  *   40        sequence word: what a read-back kernel stores last (grows with every use)
  *   44 .. 49  the closure's early report (a one-workgroup launch that ended the search)
  *   52 .. 55  the match lists' report: total and overflow count, each marked with the call's
  *             number (mcx_k1.hip)
+ *   64 .. 79  the closure's early report, second part: the frontier sizes of the batch's levels
  * A closure call may return on the early report while the rest of its batch is still queued:
  * those launches find the search over, write zeros into 0..35 and the batch's number into 40
  * after the call has returned.  They are stream-ordered in front of every later kernel, and
@@ -155,6 +158,8 @@ static inline int mcx_scratch(mcx_ctx *ctx, size_t bytes, void **out)
  */
 #define MCX_PINNED_SEQ_WORD 40u
 #define MCX_PINNED_LIST_WORD 52u
+#define MCX_PINNED_HIST_WORD 64u
+#define MCX_PINNED_WORDS 96u
 
 /* the next value of the sequence word (never 0: kernels take 0 as "do not report") */
 static inline uint32_t mcx_next_seq(mcx_ctx *ctx)

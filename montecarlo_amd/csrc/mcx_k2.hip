@@ -430,6 +430,8 @@ struct k2b_report_t {
     unsigned long long *edges;
     uint32_t *small;            /* levels of the one-workgroup kernel, handed over */
     uint32_t *seq;              /* written last */
+    uint32_t *hist;             /* K2B_BATCH words (may be null): the queue sizes of the batch's levels in front of
+                                   the launch that ended the search */
 };
 
 __global__ void __launch_bounds__(K2_THREADS)
@@ -518,6 +520,9 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
 #ifndef K2B_GMIN
 #define K2B_GMIN 16u
 #endif
+#ifndef K2B_SPREAD
+#define K2B_SPREAD 256u /* blocks a short frontier is spread over before a block's share drops below 64 */
+#endif
 
 /* append a wave's buffered entries to the next frontier: one reservation */
 __device__ __forceinline__ void k2b_flush(const uint2 *buf, uint32_t n, uint2 *__restrict__ next, uint32_t *nsize,
@@ -536,10 +541,47 @@ __device__ __forceinline__ void k2b_flush(const uint2 *buf, uint32_t n, uint2 *_
     __builtin_amdgcn_wave_barrier();
 }
 
+/* Diagnostic build (-DK2B_STAMPS, scripts/k2stamps.py; never shipped): where the time of a level
+ * goes.  Thread 0 of one block of k2b_expand (by counter-window level) and thread 0 of k2b_small
+ * (by level run in that launch; the last launch that ran levels stays) leave 100 MHz clock values
+ * at the places marked below, each behind a wait for the thread's outstanding memory operations. */
+#ifdef K2B_STAMPS
+#ifndef K2B_STAMP_BLOCK
+#define K2B_STAMP_BLOCK 0
+#endif
+__device__ unsigned long long k2b_stamp[64][16];
+__device__ unsigned long long k2s_stamp[32][8];
+#define K2_STAMP_NOW(cell)                                                                 \
+    do {                                                                                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+        (cell) = wall_clock64();                                                           \
+    } while (0)
+#define K2B_STAMP(i)                                                                       \
+    do {                                                                                   \
+        if (blockIdx.x == K2B_STAMP_BLOCK && threadIdx.x == 0 && level < 64u)              \
+            K2_STAMP_NOW(k2b_stamp[level][i]);                                             \
+    } while (0)
+/* in k2b_small: `at` = the level's number within the launch */
+#define K2S_STAMP(at, i)                                                                   \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && (at) < 32u)                                                \
+            K2_STAMP_NOW(k2s_stamp[at][i]);                                                \
+    } while (0)
+#define K2S_NOTE(at, i, value)                                                             \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && (at) < 32u)                                                \
+            k2s_stamp[at][i] = (value);                                                    \
+    } while (0)
+#else
+#define K2B_STAMP(i)
+#define K2S_STAMP(at, i)
+#define K2S_NOTE(at, i, value)
+#endif
+
 __global__ void __launch_bounds__(K2_THREADS)
 k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
            const uint2 *__restrict__ frontier, uint32_t *__restrict__ out, uint2 *__restrict__ next,
-           k2b_state_t st, uint32_t level, uint32_t sweep_waves)
+           k2b_state_t st, uint32_t level, uint32_t sweep_waves, uint32_t qcap, uint32_t dedup)
 {
     __shared__ uint32_t pre[K2_THREADS / 64][65];
     __shared__ uint32_t beg[K2_THREADS / 64][64];
@@ -549,9 +591,20 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
     __shared__ uint32_t wn[K2_THREADS / 64 + 1];
     __shared__ unsigned long long wscan[K2_THREADS / 64];
     uint32_t nbuf = 0; /* the same in all lanes of a wave */
+    K2B_STAMP(0);
+    /* the entries this block takes if the level turns out to be a short one (K2B_GMIN a block),
+     * asked for together with the level's size instead of behind it: one round trip less in
+     * the levels that are nothing but round trips */
+    const uint32_t lane_early = threadIdx.x & 63u;
+    uint2 ent_early = make_uint2(0u, 0u), ent_early64 = make_uint2(0u, 0u);
+    if (lane_early < K2B_GMIN && blockIdx.x * K2B_GMIN + lane_early < qcap)
+        ent_early = frontier[blockIdx.x * K2B_GMIN + lane_early];
+    if (blockIdx.x * 64u + lane_early < qcap) /* and if it is a long one */
+        ent_early64 = frontier[blockIdx.x * 64u + lane_early];
     const uint32_t n = st.cnt[2u * level], nh = st.cnt[2u * level + 1u];
     if (n == 0u && nh == 0u)
         return;
+    K2B_STAMP(1);
     uint32_t *nsize = &st.cnt[2u * level + 2u], *nhub = &st.cnt[2u * level + 3u];
     uint32_t *avail = st.avail;
     uint2 *nexthubs = st.hubq[(level + 1u) & 1u];
@@ -568,6 +621,7 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
          * them.  A plain load: a word this CU's L1 still holds as it was shows bits that are
          * gone, which costs a claim that fails, never a module. */
         uint32_t w[K2B_PER_LANE];
+        K2B_STAMP(3);
 #pragma unroll
         for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
             w[q] = have[q] ? avail[u[q] >> 5] : 0u;
@@ -578,8 +632,11 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
          * still sees it open, and their claims on one word are served one after the other.  So
          * a wave claims a module once: its open entries meet in a small hash table in LDS (the
          * last writer of a slot owns it and leaves its module there; an entry that finds its
-         * own module under another owner is dropped). */
-        if (__ballot(cand[0] | cand[1] | cand[2] | cand[3])) {
+         * own module under another owner is dropped).  Only towards the dependencies (`dedup`):
+         * towards the holders no module is everybody's neighbour, and the three wave barriers
+         * of the table are half a microsecond of a level that lasts five. */
+        K2B_STAMP(4);
+        if (dedup && __ballot(cand[0] | cand[1] | cand[2] | cand[3])) {
             uint32_t slot[K2B_PER_LANE];
 #pragma unroll
             for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
@@ -607,12 +664,14 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        K2B_STAMP(5);
 #pragma unroll
         for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
             old[q] = cand[q] ? atomicAnd(&avail[u[q] >> 5], ~(1u << (u[q] & 31u))) : 0u;
             rb[q] = cand[q] ? rowptr[u[q]] : 0u;
             re[q] = cand[q] ? rowptr[u[q] + 1u] : 0u;
         }
+        K2B_STAMP(6);
 #pragma unroll
         for (uint32_t q = 0; q < K2B_PER_LANE; ++q) {
             const uint32_t bit = 1u << (u[q] & 31u);
@@ -638,24 +697,32 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
         }
     };
 
-    /* the frontier, `grp` entries per wave and round: 64 when there is enough
-     * of it for the whole grid, fewer (down to K2B_GMIN) when there is not, so
-     * that a short frontier of long lists still spreads over many waves */
-    const uint32_t nwaves_all = min(gridDim.x * (K2_THREADS / 64u), sweep_waves);
+    /* The frontier, `grp` entries per BLOCK and round: 64 when there is enough of it for
+     * K2B_SPREAD blocks, fewer (down to K2B_GMIN) when there is not, so that a short frontier
+     * still spreads over that many blocks (every block with work costs the level a queue
+     * reservation, served one after the other: thinner than this, a level got slower).  The four waves of a block all take the same entries (the
+     * second to fourth read them from L1), lay their lists end to end and share the steps of
+     * that concatenation among them: the lists' lengths differ by two orders of magnitude, and
+     * a level ends with its slowest wave - a wave alone with sixteen long lists took eight
+     * steps where its neighbours took one. */
+    const uint32_t nblocks_all = min(gridDim.x, max(sweep_waves / (K2_THREADS / 64u), 1u));
     uint32_t grp = 64u;
-    while (grp > K2B_GMIN && (grp >> 1) * nwaves_all >= n)
+    while (grp > K2B_GMIN && (grp >> 1) * min(nblocks_all, K2B_SPREAD) >= n)
         grp >>= 1;
-    const uint32_t wave_all = blockIdx.x * (K2_THREADS / 64u) + wave;
-    for (uint32_t base = wave_all < nwaves_all ? wave_all * grp : n; base < n; base += nwaves_all * grp) {
+    for (uint32_t base = blockIdx.x < nblocks_all ? blockIdx.x * grp : n; base < n; base += nblocks_all * grp) {
         const uint32_t t = base + lane;
         uint32_t k0 = 0, k1 = 0;
         if (lane < grp && t < n) {
-            const uint2 ent = frontier[t];
+            const uint2 ent = (grp == K2B_GMIN && base == blockIdx.x * K2B_GMIN) ? ent_early
+                              : (grp == 64u && base == blockIdx.x * 64u)         ? ent_early64
+                                                                                 : frontier[t];
             k0 = ent.x;
             k1 = ent.y;
         }
+        K2B_STAMP(2);
         const uint32_t deg = k1 - k0;
-        scanned += deg;
+        if (wave == 0u)
+            scanned += deg; /* once per block */
         uint32_t incl = deg;
 #pragma unroll
         for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -671,7 +738,7 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t j0 = 0; j0 < total; j0 += 64u * K2B_PER_LANE) {
+        for (uint32_t j0 = 64u * K2B_PER_LANE * wave; j0 < total; j0 += K2_THREADS * K2B_PER_LANE) {
             uint32_t u[K2B_PER_LANE];
             bool have[K2B_PER_LANE];
 #pragma unroll
@@ -744,6 +811,7 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
     /* what the waves still hold goes out with one queue reservation and one add to the entry
      * count per block: a few thousand atomics on one word would take longer than the level
      * (they are served one after the other, some 12 ns each) */
+    K2B_STAMP(7);
 #pragma unroll
     for (uint32_t d = 32; d >= 1; d >>= 1)
         scanned += __shfl_down(scanned, d, 64);
@@ -752,6 +820,7 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
         wscan[wave] = scanned;
     }
     __syncthreads();
+    K2B_STAMP(8);
     if (threadIdx.x == 0u) {
         uint32_t tot = 0;
         unsigned long long sc = 0;
@@ -767,9 +836,11 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
             atomicAdd(st.edges, sc);
     }
     __syncthreads();
+    K2B_STAMP(9);
     const uint32_t at = wn[K2_THREADS / 64u] + wn[wave];
     for (uint32_t i = lane; i < nbuf; i += 64u)
         next[at + i] = buf[wave][i];
+    K2B_STAMP(10);
 }
 
 /*
@@ -797,6 +868,11 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
 #define K2B_SMALL_EVERY 2u /* the one-workgroup kernel goes in front of every so many levels */
 #endif
 #define K2S_THREADS 1024u
+#ifndef K2S_TRY_N
+#define K2S_TRY_N 600u /* frontier entries up to which a level is worth a try of the one-workgroup kernel */
+#endif
+#define K2S_HASH_BITS 12u
+#define K2S_HASH (1u << K2S_HASH_BITS) /* slots of the one-workgroup kernel's claim table: one per entry of a step */
 #define K2S_CAP 2048u
 #define K2S_PER 4u
 #ifndef K2S_LEVEL_MAX
@@ -806,8 +882,10 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
 __global__ void __launch_bounds__(K2S_THREADS)
 k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, uint32_t *__restrict__ out,
           uint2 *__restrict__ queue, uint2 *__restrict__ spill, k2b_state_t st, uint32_t level, k2b_report_t rep,
-          uint32_t seq, uint32_t only_the_end)
+          uint32_t seq, uint32_t only_the_end, uint32_t batch_base, uint32_t dedup)
 {
+    __shared__ uint16_t hid[K2S_HASH];  /* dedup: who asked last for the module that hashes here */
+    __shared__ uint32_t hmod[K2S_HASH]; /* ... and which module that was */
     __shared__ uint32_t qb[2][K2S_CAP], qe[2][K2S_CAP]; /* list start, list end */
     __shared__ uint32_t pre[K2S_CAP + 1u];               /* exclusive sums of the list lengths */
     __shared__ uint32_t wsum[K2S_THREADS / 64u];
@@ -849,6 +927,7 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
         }
         __syncthreads();
         while (n != 0u) {
+            K2S_STAMP(levels, 0);
             /* exclusive sums of the list lengths: K2S_CAP / K2S_THREADS = 2 entries per thread */
             uint32_t d[K2S_CAP / K2S_THREADS], sum = 0;
 #pragma unroll
@@ -888,36 +967,85 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                 hand_over(cur, n, 0u);
                 break;
             }
+            K2S_STAMP(levels, 1);
+            K2S_NOTE(levels, 6, n);
+            K2S_NOTE(levels, 7, total);
             ++levels;
             scanned += total;
             const uint32_t nxt = cur ^ 1u;
             for (uint32_t j0 = 0; j0 < total; j0 += K2S_THREADS * K2S_PER) {
                 uint32_t u[K2S_PER], old[K2S_PER], b[K2S_PER], e[K2S_PER];
                 bool have[K2S_PER];
+                /* largest i with pre[i] <= j, for the thread's four entries side by side: the same
+                 * number of halvings for all (from n), so that the four chains of dependent LDS
+                 * reads overlap instead of following each other (eleven reads each at n = 2048) */
+                uint32_t lo[K2S_PER], hi[K2S_PER];
+#pragma unroll
+                for (uint32_t q = 0; q < K2S_PER; ++q) {
+                    have[q] = j0 + K2S_THREADS * q + tid < total;
+                    lo[q] = 0u;
+                    hi[q] = n;
+                }
+                for (uint32_t span = n; span > 1u; span = (span + 1u) >> 1) {
+#pragma unroll
+                    for (uint32_t q = 0; q < K2S_PER; ++q) {
+                        const uint32_t mid = (lo[q] + hi[q]) >> 1;
+                        const bool go = hi[q] - lo[q] > 1u;
+                        const bool up = pre[go ? mid : lo[q]] <= j0 + K2S_THREADS * q + tid;
+                        lo[q] = go && up ? mid : lo[q];
+                        hi[q] = go && !up ? mid : hi[q];
+                    }
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < K2S_PER; ++q) {
                     const uint32_t j = j0 + K2S_THREADS * q + tid;
-                    have[q] = j < total;
-                    uint32_t lo = 0, hi = n; /* largest i with pre[i] <= j */
-                    while (hi - lo > 1u) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (pre[mid] <= j)
-                            lo = mid;
-                        else
-                            hi = mid;
-                    }
-                    u[q] = have[q] ? col[qb[cur][lo] + (j - pre[lo])] : 0u;
+                    u[q] = have[q] ? col[qb[cur][lo[q]] + (j - pre[lo[q]])] : 0u;
                 }
+                K2S_STAMP(levels - 1u, 2);
 #pragma unroll
                 for (uint32_t q = 0; q < K2S_PER; ++q) /* a look first (see k2b_expand) */
                     old[q] = have[q] ? __hip_atomic_load(&avail[u[q] >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                K2S_STAMP(levels - 1u, 3);
+                bool cand[K2S_PER];
+#pragma unroll
+                for (uint32_t q = 0; q < K2S_PER; ++q)
+                    cand[q] = ((old[q] >> (u[q] & 31u)) & 1u) != 0u;
+                if (dedup) {
+                    /* towards the dependencies the lists of a level name the same few modules over
+                     * and over; all of a step's looks see such a module open, and their claims on
+                     * its word would be served one after the other (3000 entries: 6 us).  One
+                     * entry per module claims: the last writer of a hash slot owns it and leaves
+                     * its module there, an entry that finds its own module under another owner is
+                     * dropped (k2b_expand does the same per wave). */
+                    uint32_t slot[K2S_PER];
+#pragma unroll
+                    for (uint32_t q = 0; q < K2S_PER; ++q) {
+                        slot[q] = (u[q] * 0x9E3779B1u) >> (32u - K2S_HASH_BITS);
+                        if (cand[q])
+                            hid[slot[q]] = (uint16_t)(K2S_PER * tid + q);
+                    }
+                    __syncthreads();
+                    bool owner[K2S_PER];
+#pragma unroll
+                    for (uint32_t q = 0; q < K2S_PER; ++q) {
+                        owner[q] = cand[q] && hid[slot[q]] == (uint16_t)(K2S_PER * tid + q);
+                        if (owner[q])
+                            hmod[slot[q]] = u[q];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t q = 0; q < K2S_PER; ++q)
+                        if (cand[q] && !owner[q] && hmod[slot[q]] == u[q])
+                            cand[q] = false;
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < K2S_PER; ++q) {
-                    const bool open = ((old[q] >> (u[q] & 31u)) & 1u) != 0u;
+                    const bool open = cand[q];
                     old[q] = open ? atomicAnd(&avail[u[q] >> 5], ~(1u << (u[q] & 31u))) : 0u;
                     b[q] = open ? rowptr[u[q]] : 0u;
                     e[q] = open ? rowptr[u[q] + 1u] : 0u;
                 }
+                K2S_STAMP(levels - 1u, 4);
 #pragma unroll
                 for (uint32_t q = 0; q < K2S_PER; ++q) {
                     const uint32_t bit = 1u << (u[q] & 31u);
@@ -934,6 +1062,7 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                 }
             }
             __syncthreads();
+            K2S_STAMP(levels - 1u, 5);
             const uint32_t nn = nnext_sh;
             if (nn > K2S_CAP) {
                 /* the spilled entries were written by this block: make them visible to its own reads */
@@ -967,6 +1096,10 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
         /* (a launch that found the search over already leaves the word to the batch's report) */
         const bool tell = seq != 0u && (only_the_end == 0u || (handed == 0u && mine));
         if (tell) {
+            if (only_the_end && rep.hist) /* how long the frontiers of this batch were: the host places the
+                                             next search's one-workgroup launches by them */
+                for (uint32_t l = batch_base; l < level && l - batch_base < K2B_BATCH; ++l)
+                    rep.hist[l - batch_base] = st.cnt[2u * l];
             rep.sizes[0] = only_the_end ? level : left_q;
             rep.sizes[1] = only_the_end ? seq : left_h;
             *rep.edges = edges;
@@ -1258,6 +1391,8 @@ int mcx_dep_graph_load(mcx_ctx *ctx, const uint32_t *rowptr, const uint32_t *col
             ctx->n_slices = 0;
     }
     ctx->bfs_depth[0] = ctx->bfs_depth[1] = 0;
+    ctx->bfs_sizes[0].clear();
+    ctx->bfs_sizes[1].clear();
     ctx->graph_loaded = true;
     return MCX_OK;
 }
@@ -1450,14 +1585,16 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     rep.edges = (unsigned long long *)(d_sizes + 2 * K2B_BATCH);
     rep.small = d_sizes + 2 * K2B_BATCH + 2;
     rep.seq = d_sizes + MCX_PINNED_SEQ_WORD;
+    rep.hist = nullptr;
     /* first the one-workgroup kernel, as far as the levels stay small (most closures of a few
      * modules end there: one launch, which also reports).  A search that needed per-level
      * launches last time in this direction will most likely do so again: its first batch is
      * then enqueued without a look in between. */
     const bool expect_handover = ctx->bfs_depth[direction] != 0u;
     const uint32_t seq0 = expect_handover ? 0u : mcx_next_seq(ctx);
+    const uint32_t dedup = direction == MCX_CLOSURE_DEPS ? 1u : 0u;
     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[0], queue[1], st, 0u, rep, seq0,
-                                                  0u);
+                                                  0u, 0u, dedup);
     HIPCHK(ctx, hipGetLastError());
     if (!expect_handover && mcx_wait_seq(ctx, seq0))
         return MCX_E_HIP;
@@ -1487,6 +1624,15 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
         end_rep.edges = (unsigned long long *)(d_sizes + K2B_PINNED_END + 2u);
         end_rep.small = d_sizes + K2B_PINNED_END + 4u;
         end_rep.seq = rep.seq;
+        end_rep.hist = d_sizes + MCX_PINNED_HIST_WORD;
+        const uint32_t *h_hist = ctx->h_pinned + MCX_PINNED_HIST_WORD;
+        /* the frontier sizes of the last search in this direction, per-level launch by per-level
+         * launch: searches over one graph tend to have the same shape, and the one-workgroup
+         * kernel is worth a launch only in front of a level that will be short */
+        const std::vector<uint32_t> last = ctx->bfs_sizes[direction];
+        std::vector<uint32_t> &mine = ctx->bfs_sizes[direction];
+        mine.clear();
+        uint32_t g0 = 0; /* per-level launches enqueued by the batches before this one */
         /* Towards the dependencies every list leads to the same few modules everything needs:
          * at the start of a level each wave still sees them open and claims them, and claims
          * on one cache line are served one after the other - the first step of such a level
@@ -1507,13 +1653,18 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                  * short again, less one: while the frontier is large that launch only looks and
                  * returns (a search that shrinks earlier than the last one runs its short levels
                  * as launches of their own until then) */
-                if (b != 0u && b % K2B_SMALL_EVERY == 0u && level + 1u >= hint)
+                const uint32_t g = g0 + b;
+                const bool known = g < last.size();
+                const bool try_small = known ? (last[g] != 0u && last[g] <= K2S_TRY_N)
+                                             : (b % K2B_SMALL_EVERY == 0u && level + 1u >= hint);
+                if (b != 0u && try_small)
                     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[level & 1u],
                                                                   queue[(level + 1u) & 1u], st, level, end_rep, seq_end,
-                                                                  1u);
+                                                                  1u, base, dedup);
                 k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, queue[level & 1u],
                                                                       (uint32_t *)d_out_bitmap,
-                                                                      queue[(level + 1u) & 1u], st, level, sweep_waves);
+                                                                      queue[(level + 1u) & 1u], st, level, sweep_waves,
+                                                                      V, dedup);
             }
             HIPCHK(ctx, hipGetLastError());
             k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, rep, mcx_next_seq(ctx));
@@ -1524,6 +1675,8 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                 /* a one-workgroup launch of this batch ended the search: every level before the
                  * one it was launched for had a frontier */
                 lv += h_end[0] - base;
+                for (uint32_t b = 0; b < h_end[0] - base && b < K2B_BATCH; ++b)
+                    mine.push_back(h_hist[b]);
                 ended_edges = *(const unsigned long long *)(h_end + 2);
                 ended_small = h_end[4];
                 ended_early = true;
@@ -1534,9 +1687,11 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                     done = true;
                     break;
                 }
+                mine.push_back(sizes[2u * b + 1u] ? 0xFFFFFFFFu : sizes[2u * b]); /* a level with hubs is never short */
                 ++lv;
             }
             base += batch;
+            g0 += batch;
         }
         /* 0: the one-workgroup kernel did it all */
         ctx->bfs_depth[direction] = lv > K2B_BATCH ? K2B_BATCH : lv;
@@ -1548,6 +1703,17 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
         *levels = (ended_early ? ended_small : h_small[0]) + lv;
     return MCX_OK;
 }
+
+#ifdef K2B_STAMPS
+int mcx_debug_k2b_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k2b_stamp), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : -1;
+}
+int mcx_debug_k2s_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k2s_stamp), sizeof(unsigned long long) * 32 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int mcx_dep_closure(mcx_ctx *ctx, const uint8_t *in_flags, const uint32_t *seed_bitmap, uint32_t *out_bitmap,
                     int direction, uint64_t *edges_scanned, uint32_t *levels)
