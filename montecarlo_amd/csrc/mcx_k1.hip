@@ -899,7 +899,7 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
 #endif
 #define K1T_RCAP (K1T_RPT * K1T_THREADS) /* candidate runs waiting for the screen */
 #ifndef K1T_BCAP
-#define K1T_BCAP 288u        /* (string, large group) pairs waiting for the second index; a probe
+#define K1T_BCAP 272u        /* (string, large group) pairs waiting for the second index; a probe
                                 step adds up to K1T_THREADS of them */
 #endif
 #ifndef K1T_SCAP
@@ -964,6 +964,7 @@ struct k1t_shared_t {
     uint32_t big_key[K1T_BCAP], big_start[K1T_BCAP], big_count[K1T_BCAP], big_rest[K1T_BCAP];
     uint32_t surv[K1T_SCAP];
     uint32_t nruns_sh, nbig_sh, nsurv_sh, wsum[K1T_WAVES];
+    uint8_t mark[K1T_WAVES][64]; /* screen: where runs start inside a wave's window of 64 candidates */
 };
 
 /* The kernel's work on one tile.  INPLACE: the tile's strings do not fit the staging buffer and are
@@ -998,6 +999,7 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
     auto &nbig_sh = sh.nbig_sh;
     auto &nsurv_sh = sh.nsurv_sh;
     auto &wsum = sh.wsum;
+    auto &mark = sh.mark;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1183,6 +1185,7 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
             __syncthreads();
         }
         const uint32_t ncand = run_cum[nr];
+        uint32_t wrun = 0; /* the run of the wave's first candidate of the last step (the same in all its lanes) */
         uint32_t bound = nsurv_sh; /* no more survivors than this are queued */
         for (uint32_t c0 = 0; c0 < ncand; c0 += K1T_THREADS) {
             if (bound + K1T_THREADS > K1T_SCAP) {
@@ -1195,15 +1198,51 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
             const uint32_t c = c0 + tid;
             bool pass = false;
             uint32_t e = 0;
+            /* The run that holds candidate c: largest r with run_cum[r] <= c.  The 64 candidates
+             * of a wave are consecutive, and so are their runs: the wave keeps the run of its
+             * first candidate from step to step (wrun: the next 64 sums are looked at by a lane
+             * each, and the ballot of those that lie at or below the first candidate says how
+             * far to move on), and a lane's run is that one plus the number of runs that start
+             * inside the wave's window at or before the lane's place - the starts are marked in
+             * 64 bytes of LDS, and a ballot of the marks is counted up to the lane.  A bisection
+             * per candidate was ten dependent LDS reads and sixty instructions a pass. */
+            const uint32_t cw = c0 + 64u * wave; /* the wave's first candidate */
+            uint32_t lo = 0;
+            bool by_bisection = false;
+            if (cw < ncand) {
+                uint32_t v, adv;
+                do {
+                    v = run_cum[min(wrun + 1u + lane, nr)]; /* start of run wrun + 1 + lane (ncand beyond the last) */
+                    adv = (uint32_t)__popcll(__ballot(v <= cw));
+                    wrun += adv;
+                } while (adv == 64u);
+                wrun = __builtin_amdgcn_readfirstlane(wrun);
+                /* v: the starts of runs wrun - adv + 1 + lane; those behind cw and inside the window mark their place */
+                const uint32_t v_last = __builtin_amdgcn_readlane(v, 63);
+                by_bisection = v_last < cw + 64u && v_last < ncand; /* more than 64 - adv runs start in the window */
+                mark[wave][lane] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (v > cw && v < cw + 64u && v < ncand)
+                    mark[wave][v - cw] = 1u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned long long starts = __ballot(mark[wave][lane] != 0u);
+                lo = wrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u)) +
+                     (uint32_t)((starts >> lane) & 1ull);
+            }
             if (c < ncand) {
-                /* the run that holds candidate c: largest r with run_cum[r] <= c */
-                uint32_t lo = 0, hi = nr;
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (run_cum[mid] <= c)
-                        lo = mid;
-                    else
-                        hi = mid;
+                if (by_bisection) { /* a window of runs of one: the long way round */
+                    uint32_t hi = nr;
+                    lo = 0;
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (run_cum[mid] <= c)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
                 }
                 const uint32_t k = run_start[lo] + (c - run_cum[lo]), slot = run_cnt[lo] >> 26;
                 const uint32_t sg = T.sig[k];
@@ -1411,6 +1450,10 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
         rbound += K1T_THREADS;
         bbound += K1T_THREADS;
         const uint32_t pr = p0 + tid;
+        /* words of the longest key among this wave's items: that of its last one */
+        const uint32_t pr_last = min(p0 + 64u * wave + 63u, nprobe - 1u);
+        const uint32_t nkw =
+            __builtin_amdgcn_readfirstlane((key_lens[nstr == 1u ? pr_last : __umulhi(pr_last, nstr_magic)] + 3u) >> 2);
         if (pr < nprobe) {
             /* key length by key length over all strings of the tile, not string by string: the
              * lanes of a step then hash keys of one length, and what the later phases are handed
@@ -1420,15 +1463,25 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
             const uint32_t KL = key_lens[li];
             const uint32_t len = str_len[slot];
             if (KL <= len) {
+                /* the key's words and their hash: only as many words as the longest key of this
+                 * wave's lanes reaches into (the lanes of a wave hash keys of one length, two at a
+                 * boundary; the lengths ascend with the item number) - the same for the whole wave,
+                 * so the words behind are skipped by a branch, not computed and thrown away */
                 uint32_t kw[MCX_KEY_MAX / 4];
+                uint32_t a = mcx_key_hash_start(KL);
 #pragma unroll
-                for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
-                    kw[k] = (4u * k < KL) ? word_of(slot, 4u * k) : 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k)
-                    if ((KL >> 2) == k && (KL & 3u))
-                        kw[k] &= 0xFFFFFFFFu >> (8u * (4u - (KL & 3u)));
-                const uint32_t a = mcx_key_hash(kw, KL), my_tag = mcx_key_tag(a) * 0x01010101u;
+                for (uint32_t k = 0; k < MCX_KEY_MAX / 4; ++k) {
+                    kw[k] = 0u;
+                    if (k < nkw) {
+                        uint32_t wk = (4u * k < KL) ? word_of(slot, 4u * k) : 0u;
+                        if ((KL >> 2) == k && (KL & 3u))
+                            wk &= 0xFFFFFFFFu >> (8u * (4u - (KL & 3u)));
+                        kw[k] = wk;
+                        a = 4u * k < KL ? mcx_key_hash_step(a, wk) : a;
+                    }
+                }
+                a = mcx_key_hash_end(a);
+                const uint32_t my_tag = mcx_key_tag(a) * 0x01010101u;
                 /* four tag bytes a step: nearly every walk ends inside the first word */
                 bool done = false;
                 for (uint32_t at = a & T.slot_mask; !done; at = (at + 4u) & T.slot_mask) {

@@ -152,19 +152,31 @@ MCX_HD uint32_t mcx_key_tag(uint32_t hash)
 }
 
 /* Hash of a key of `len` <= MCX_KEY_MAX bytes held in little-endian words
- * kw[0..7] (bytes past `len` must be zero).  It only spreads the keys over the
- * table: a probe compares the key itself. */
+ * kw[0..7] (bytes past `len` must be zero): over the words the key reaches
+ * into, no further - a probe that knows its key is short reads and mixes only
+ * those.  It only spreads the keys over the table: a probe compares the key
+ * itself. */
+MCX_HD uint32_t mcx_key_hash_step(uint32_t a, uint32_t word)
+{
+    a = (a ^ word) * 0x01000193u;
+    return a ^ (a >> 15);
+}
+MCX_HD uint32_t mcx_key_hash_start(uint32_t len)
+{
+    return 0x811C9DC5u ^ (len * 0x9E3779B1u);
+}
+MCX_HD uint32_t mcx_key_hash_end(uint32_t a)
+{
+    a *= 0x7FEB352Du;
+    return a ^ (a >> 16);
+}
 MCX_HD uint32_t mcx_key_hash(const uint32_t *kw, uint32_t len)
 {
-    uint32_t a = 0x811C9DC5u ^ (len * 0x9E3779B1u);
+    uint32_t a = mcx_key_hash_start(len);
     MCX_UNROLL
-    for (uint32_t k = 0; k < MCX_KEY_MAX / 4u; ++k) {
-        a = (a ^ kw[k]) * 0x01000193u;
-        a ^= a >> 15;
-    }
-    a *= 0x7FEB352Du;
-    a ^= a >> 16;
-    return a;
+    for (uint32_t k = 0; k < MCX_KEY_MAX / 4u; ++k)
+        a = 4u * k < len ? mcx_key_hash_step(a, kw[k]) : a;
+    return mcx_key_hash_end(a);
 }
 
 /* Bloom bit (0..254) of the gram whose four bytes form the word g */

@@ -55,6 +55,8 @@ int main(int argc, char **argv)
     std::map<uint32_t, uint64_t> surv_by_nseg, cand_by_gsize, runs_by_size, cand_by_runsize;
     std::map<std::string, uint64_t> fp_shape;
     std::map<uint64_t, uint64_t> cost_hist;
+    std::vector<uint32_t> tile_pat;  /* patterns of the survivors of the current tile */
+    uint64_t tiles = 0, tile_surv = 0, tile_distinct = 0, shared2 = 0, shared4 = 0, shared8 = 0, shared16 = 0;
     std::vector<uint32_t> tile_cost; /* run lengths of the survivors of the current tile of 64 strings, in order */
     uint64_t wave_sum = 0, wave_max64 = 0;
     uint32_t big_shown = 0;
@@ -74,6 +76,21 @@ int main(int argc, char **argv)
                 wave_max64 += 64ull * mx;
             }
             tile_cost.clear();
+            /* how many of a tile's program runs share their pattern with other runs of the tile */
+            if (!tile_pat.empty()) {
+                std::map<uint32_t, uint32_t> by;
+                for (uint32_t k : tile_pat) by[k]++;
+                ++tiles;
+                tile_surv += tile_pat.size();
+                tile_distinct += by.size();
+                for (auto &kv : by) {
+                    if (kv.second >= 2) shared2 += kv.second;
+                    if (kv.second >= 4) shared4 += kv.second;
+                    if (kv.second >= 8) shared8 += kv.second;
+                    if (kv.second >= 16) shared16 += kv.second;
+                }
+                tile_pat.clear();
+            }
         }
         const uint32_t len = s_off[i + 1] - s_off[i];
         HostStr s{S.data() + s_off[i], len};
@@ -131,6 +148,7 @@ int main(int argc, char **argv)
                                       ? mcx_prog_match(HostProg{t.ext.data()}, slot[MCX_SLOT_DIR], slot[0], s, len, t.sets.data())
                                       : mcx_prog_match(HostProg{slot}, MCX_SLOT_BODY, slot[0], s, len, t.sets.data());
                         tile_cost.push_back((uint32_t)(g_words - words0));
+                        tile_pat.push_back(k);
                         cost_hist[std::min<uint64_t>(g_words - words0, 63)]++;
                         if (ok) ++match;
                         else if (fp_shape.size() < 100000) {
@@ -153,6 +171,9 @@ int main(int argc, char **argv)
     for (auto &kv : cand_by_gsize) printf("  candidates from groups <= %u: %.2f per string\n", kv.first, (double)kv.second / N);
     printf("program runs: %.1f string words read per survivor; lanes busy if a wave waits for its longest run: %.1f of 64\n",
            (double)wave_sum / surv, 64.0 * wave_sum / wave_max64);
+    printf("tiles of 64 strings: %.1f runs a tile over %.1f distinct patterns; runs whose pattern has >= 2 / 4 / 8 / 16 runs in the tile: %.1f%% / %.1f%% / %.1f%% / %.1f%%\n",
+           (double)tile_surv / tiles, (double)tile_distinct / tiles, 100.0 * shared2 / tile_surv, 100.0 * shared4 / tile_surv,
+           100.0 * shared8 / tile_surv, 100.0 * shared16 / tile_surv);
     for (auto &kv : cost_hist) printf("  runs reading %llu words: %.3f per string\n", (unsigned long long)kv.first, (double)kv.second / N);
     for (auto &kv : runs_by_size)
         printf("  runs of up to %u candidates: %.2f per string, %.2f candidates\n", kv.first, (double)kv.second / N,
