@@ -14,7 +14,8 @@
  *   roots [-d <modules dir>] [-p <proc modules file>]
  *       the dashboard's module list for this host (reference
  *       desktop/ui.py:1565-1599) without its "used driver" column: loaded
- *       modules with a safe name and a hardware alias that nothing holds.
+ *       modules with a safe name and a hardware alias that nothing holds, each
+ *       with the dashboard's "(In Use)" / "(Idle)" tag (ui.py:1579-1590).
  *   bench [-d <modules dir>] [-n <strings>] [-r <repetitions>]
  *       times the batch path on this host's tables: <strings> modalias strings
  *       made from the lines of modules.alias (every wildcard filled in) against
@@ -230,7 +231,10 @@ static int cmd_roots(int argc, char **argv)
     uint32_t shown = 0;
     for (uint32_t v = 0; v < V; ++v)
         if (out[v] & MCX_O_ROOT) {
-            printf("%s\n", mcx_modtab_module_name(t, v));
+            /* the dashboard's status tag (reference desktop/ui.py:1579-1590): device links under the
+             * module's name or its name variant on the pci, usb or pcmcia bus of THIS host */
+            const char *name = mcx_modtab_module_name(t, v);
+            printf("%s%s\n", name, mc_driver_is_in_use(name) ? " (In Use)" : " (Idle)");
             ++shown;
         }
     fprintf(stderr, "%u of %u modules listed (%u loaded modules are not in the tables)\n", shown, V, unknown);

@@ -83,8 +83,22 @@ def test_match_and_roots(tmp_path):
     # hardware alias and a safe name that nothing holds are listed
     r = run("roots", "-d", str(tmp_path), "-p", str(tmp_path / "proc_modules"))
     assert r.returncode == 0, r.stderr
-    assert r.stdout.split() == ["e1000e", "rtw88_8821cu"]
+    assert [ln.split()[0] for ln in r.stdout.splitlines()] == ["e1000e", "rtw88_8821cu"]
+    assert all(ln.endswith(" (Idle)") or ln.endswith(" (In Use)") for ln in r.stdout.splitlines())
     assert "1 loaded modules are not in the tables" in r.stderr
+
+
+@pytest.mark.gpu
+def test_roots_status_tag(tmp_path, tree):
+    """the status tag of a listed module, on the fake sysfs tree (test build of the tool): a usb
+    interface there is bound to `rtw_8821cu`, the name variant of module rtw88_8821cu (reference
+    montecarlo/libmontecarlo.c:552-559), nothing is bound to e1000e"""
+    (tmp_path / "modules.alias").write_text(ALIAS_TEXT)
+    (tmp_path / "modules.dep").write_text(DEP_TEXT)
+    (tmp_path / "proc_modules").write_text(PROC_MODULES)
+    r = run("roots", "-d", str(tmp_path), "-p", str(tmp_path / "proc_modules"), cli=CLI_SEAMS)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ["e1000e (Idle)", "rtw88_8821cu (In Use)"]
 
 
 def test_bench_usage():
