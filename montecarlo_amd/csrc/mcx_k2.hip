@@ -509,6 +509,13 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
  * entries wait in a per-wave LDS buffer and are appended to the next frontier
  * with one queue reservation per buffer.
  *
+ * LOOK = false leaves the look out: a level of a few thousand entries is nothing but
+ * round trips, and the look is one of them (a claim that fails costs an atomic, the row
+ * pointers asked for in vain two loads).  The host chooses by the size the level had in
+ * the last search of this direction, and only towards the holders: towards the
+ * dependencies the look is what keeps a thousand blocks from queueing up at the words of
+ * the modules everything needs.
+ *
  * A hub (10^4 holders and more are common: the core modules everything needs)
  * would keep its wave busy long after the rest of the level is done.  A newly
  * found hub goes to the hub list of the next level instead of its frontier,
@@ -517,12 +524,29 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
  */
 #define K2B_PER_LANE 4u
 #define K2B_BUF 512u
+#ifndef K2B_LOOK_MAX
+#define K2B_LOOK_MAX 8192u /* frontier entries up to which a level towards the holders claims without a look (0: never) */
+#endif
 #ifndef K2B_GMIN
 #define K2B_GMIN 16u
 #endif
 #ifndef K2B_SPREAD
 #define K2B_SPREAD 256u /* blocks a short frontier is spread over before a block's share drops below 64 */
 #endif
+
+/* running sums over the 64 lanes of a wave by the data-parallel primitives: four steps inside
+ * the rows of sixteen lanes (lanes without a lane that far to their left add 0), then the last
+ * lane of row 0 to row 1 and of row 2 to row 3, then the last lane of row 1 to rows 2 and 3 */
+__device__ __forceinline__ uint32_t k2_wave_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
 
 /* append a wave's buffered entries to the next frontier: one reservation */
 __device__ __forceinline__ void k2b_flush(const uint2 *buf, uint32_t n, uint2 *__restrict__ next, uint32_t *nsize,
@@ -578,6 +602,7 @@ __device__ unsigned long long k2s_stamp[32][8];
 #define K2S_NOTE(at, i, value)
 #endif
 
+template <bool LOOK>
 __global__ void __launch_bounds__(K2_THREADS)
 k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
            const uint2 *__restrict__ frontier, uint32_t *__restrict__ out, uint2 *__restrict__ next,
@@ -622,12 +647,18 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
          * gone, which costs a claim that fails, never a module. */
         uint32_t w[K2B_PER_LANE];
         K2B_STAMP(3);
+        if (LOOK) {
 #pragma unroll
-        for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
-            w[q] = have[q] ? avail[u[q] >> 5] : 0u;
+            for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
+                w[q] = have[q] ? avail[u[q] >> 5] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
-            cand[q] = ((w[q] >> (u[q] & 31u)) & 1u) != 0u;
+            for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
+                cand[q] = ((w[q] >> (u[q] & 31u)) & 1u) != 0u;
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < K2B_PER_LANE; ++q)
+                cand[q] = have[q];
+        }
         /* At the start of a level every wave that meets one of the modules everything needs
          * still sees it open, and their claims on one word are served one after the other.  So
          * a wave claims a module once: its open entries meet in a small hash table in LDS (the
@@ -723,13 +754,7 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
         const uint32_t deg = k1 - k0;
         if (wave == 0u)
             scanned += deg; /* once per block */
-        uint32_t incl = deg;
-#pragma unroll
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d)
-                incl += o;
-        }
+        const uint32_t incl = k2_wave_incl(deg);
         const uint32_t total = __shfl(incl, 63, 64);
         pre[wave][lane] = incl - deg;
         beg[wave][lane] = k0;
@@ -878,6 +903,9 @@ k2b_expand(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col
 #ifndef K2S_LEVEL_MAX
 #define K2S_LEVEL_MAX 4096u
 #endif
+#ifndef K2S_LOOK_MAX
+#define K2S_LOOK_MAX 1024u /* adjacency entries of a level up to which it claims without a look (0: never) */
+#endif
 
 __global__ void __launch_bounds__(K2S_THREADS)
 k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, uint32_t *__restrict__ out,
@@ -936,13 +964,7 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                 d[k] = i < n ? qe[cur][i] - qb[cur][i] : 0u;
                 sum += d[k];
             }
-            uint32_t incl = sum;
-#pragma unroll
-            for (uint32_t s = 1; s < 64; s <<= 1) {
-                const uint32_t o = __shfl_up(incl, s, 64);
-                if (lane >= s)
-                    incl += o;
-            }
+            const uint32_t incl = k2_wave_incl(sum);
             if (lane == 63u)
                 wsum[wave] = incl;
             if (tid == 0)
@@ -1002,14 +1024,20 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                     u[q] = have[q] ? col[qb[cur][lo[q]] + (j - pre[lo[q]])] : 0u;
                 }
                 K2S_STAMP(levels - 1u, 2);
-#pragma unroll
-                for (uint32_t q = 0; q < K2S_PER; ++q) /* a look first (see k2b_expand) */
-                    old[q] = have[q] ? __hip_atomic_load(&avail[u[q] >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                K2S_STAMP(levels - 1u, 3);
                 bool cand[K2S_PER];
+                if (dedup != 0u || K2S_LOOK_MAX == 0u || total > K2S_LOOK_MAX) {
 #pragma unroll
-                for (uint32_t q = 0; q < K2S_PER; ++q)
-                    cand[q] = ((old[q] >> (u[q] & 31u)) & 1u) != 0u;
+                    for (uint32_t q = 0; q < K2S_PER; ++q) /* a look first (see k2b_expand) */
+                        old[q] = have[q] ? __hip_atomic_load(&avail[u[q] >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    K2S_STAMP(levels - 1u, 3);
+#pragma unroll
+                    for (uint32_t q = 0; q < K2S_PER; ++q)
+                        cand[q] = ((old[q] >> (u[q] & 31u)) & 1u) != 0u;
+                } else { /* a short level towards the holders: no look (see k2b_expand) */
+#pragma unroll
+                    for (uint32_t q = 0; q < K2S_PER; ++q)
+                        cand[q] = have[q];
+                }
                 if (dedup) {
                     /* towards the dependencies the lists of a level name the same few modules over
                      * and over; all of a step's looks see such a module open, and their claims on
@@ -1048,11 +1076,22 @@ k2b_small(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                 K2S_STAMP(levels - 1u, 4);
 #pragma unroll
                 for (uint32_t q = 0; q < K2S_PER; ++q) {
+                    /* the wave's new entries numbered by ballot: one add to the level's count per wave
+                     * (an add per lane to one LDS word is served lane after lane) */
                     const uint32_t bit = 1u << (u[q] & 31u);
-                    if (!(old[q] & bit))
+                    const bool got = (old[q] & bit) != 0u;
+                    const unsigned long long m = __ballot(got);
+                    if (m == 0ull)
+                        continue;
+                    uint32_t first = 0;
+                    if (lane == 0u)
+                        first = atomicAdd(&nnext_sh, (uint32_t)__popcll(m));
+                    first = __shfl(first, 0, 64);
+                    if (!got)
                         continue;
                     atomicOr(&out[u[q] >> 5], bit);
-                    const uint32_t at2 = atomicAdd(&nnext_sh, 1u);
+                    const uint32_t at2 = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     if (at2 < K2S_CAP) {
                         qb[nxt][at2] = b[q];
                         qe[nxt][at2] = e[q];
@@ -1661,10 +1700,15 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                     k2b_small<<<1, K2S_THREADS, 0, ctx->stream>>>(rp, cl, (uint32_t *)d_out_bitmap, queue[level & 1u],
                                                                   queue[(level + 1u) & 1u], st, level, end_rep, seq_end,
                                                                   1u, base, dedup);
-                k2b_expand<<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(rp, cl, queue[level & 1u],
-                                                                      (uint32_t *)d_out_bitmap,
-                                                                      queue[(level + 1u) & 1u], st, level, sweep_waves,
-                                                                      V, dedup);
+                /* without the look where the last search's level was short (a wrong guess costs time only) */
+                if (dedup == 0u && known && last[g] <= K2B_LOOK_MAX)
+                    k2b_expand<false><<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(
+                        rp, cl, queue[level & 1u], (uint32_t *)d_out_bitmap, queue[(level + 1u) & 1u], st, level,
+                        sweep_waves, V, dedup);
+                else
+                    k2b_expand<true><<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(
+                        rp, cl, queue[level & 1u], (uint32_t *)d_out_bitmap, queue[(level + 1u) & 1u], st, level,
+                        sweep_waves, V, dedup);
             }
             HIPCHK(ctx, hipGetLastError());
             k2b_publish<<<1, 64, 0, ctx->stream>>>(st.cnt, 2u * base, 2u * batch, rep, mcx_next_seq(ctx));
