@@ -903,7 +903,10 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                                 step adds up to K1T_THREADS of them */
 #endif
 #ifndef K1T_SCAP
-#define K1T_SCAP 1024u       /* survivors waiting for a program run                  */
+#define K1T_SCAP 960u        /* survivors waiting for a program run                  */
+#endif
+#ifndef K1T_LOWER
+#define K1T_LOWER 1          /* 0: program runs without the strings' sets of lower-case positions (timing experiments) */
 #endif
 #define K1T_SUB_MAX_LEN 67u  /* strings up to this length go through the second index: one
                                 lane per 4-byte window; longer ones have the whole group screened */
@@ -964,6 +967,7 @@ struct k1t_shared_t {
     uint32_t big_key[K1T_BCAP], big_start[K1T_BCAP], big_count[K1T_BCAP], big_rest[K1T_BCAP];
     uint32_t surv[K1T_SCAP];
     uint32_t nruns_sh, nbig_sh, nsurv_sh, wsum[K1T_WAVES];
+    uint32_t lowm[K1T_MAX_SPB][2]; /* per string: the positions below 64 that hold a lower-case letter */
     uint8_t mark[K1T_WAVES][64]; /* screen: where runs start inside a wave's window of 64 candidates */
 };
 
@@ -1000,6 +1004,7 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
     auto &nsurv_sh = sh.nsurv_sh;
     auto &wsum = sh.wsum;
     auto &mark = sh.mark;
+    auto &lowm = sh.lowm;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1061,7 +1066,24 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
         for (uint32_t slot = wave; slot < nstr; slot += K1T_WAVES) {
             const uint32_t len = str_len[slot];
             const LdsStr str{(lds_words_t)str_w, str_at[slot]};
-            for (uint32_t q = lane; q + 4u <= len; q += 64u) {
+            /* the first 64 positions also say where the string has lower-case letters (the start
+             * positions of the program runs' tag segments: mcx_prog_match); the words of the last
+             * three reach past the string's end, which the staging buffer allows */
+            {
+                const uint32_t w = lane < len ? str.word(lane) : 0u;
+                if (lane + 4u <= len) {
+                    const uint32_t bit = mcx_gram_bit(w);
+                    atomicOr(&bloom[slot][bit >> 5], 1u << (bit & 31u));
+                }
+                if (K1T_LOWER) {
+                    const unsigned long long lw = __ballot(lane < len && mcx_is_lower(w & 0xFFu));
+                    if (lane == 0u) {
+                        lowm[slot][0] = (uint32_t)lw;
+                        lowm[slot][1] = (uint32_t)(lw >> 32);
+                    }
+                }
+            }
+            for (uint32_t q = lane + 64u; q + 4u <= len; q += 64u) {
                 const uint32_t bit = mcx_gram_bit(str.word(q));
                 atomicOr(&bloom[slot][bit >> 5], 1u << (bit & 31u));
             }
@@ -1134,7 +1156,9 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
             ok = (hdr & 1u) != 0u || len != 0u;
 #else
             if (use_lds)
-                ok = mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets);
+                ok = mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets,
+                                    (uint64_t)lowm[slot][0] | ((uint64_t)lowm[slot][1] << 32),
+                                    K1T_LOWER != 0 && len <= 64u);
             else
                 ok = mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len, T.norm_dash}, len, T.sets);
 #endif
@@ -1556,6 +1580,7 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
                uint32_t *__restrict__ count, const k1_list_t L)
 {
+    static_assert(K1T_MIN_WAVES != 6 || sizeof(k1t_shared_t<0>) <= 26880u, "six blocks per CU: 26 880 bytes of LDS each");
     __shared__ k1t_shared_t<MODE> sh;
     const uint32_t t0 = blockIdx.x * spb;
     const uint32_t gbase = s_off[t0], gend = s_off[t0 + min(spb, N - t0)];

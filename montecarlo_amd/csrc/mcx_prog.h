@@ -329,9 +329,30 @@ MCX_HD bool mcx_seg_rest(const Prog &p, const mcx_seg_t &g, uint32_t first_chunk
  * start positions covered by one string word are screened at once by a
  * zero-byte test on word ^ literal.
  */
+MCX_HD bool mcx_is_lower(uint32_t c)
+{
+    return c - (uint32_t)'a' < 26u;
+}
+
+/* the set of positions of lower-case letters in s[0..len), len <= 64 (the host's way; the tile
+ * kernel takes it from a ballot of the lanes that build the string's gram set) */
+template <class Str>
+MCX_HD uint64_t mcx_lower_set(const Str &s, uint32_t len)
+{
+    uint64_t m = 0;
+    for (uint32_t q = 0; q < len && q < 64u; ++q)
+        m |= (uint64_t)(mcx_is_lower(s.byte(q)) ? 1u : 0u) << q;
+    return m;
+}
+
+/* `lower`: the set of positions q < 64 with a lower-case letter at s[q], for a string of at
+ * most 64 bytes (pass have_lower = false otherwise).  In an alias table nearly every segment
+ * behind a star starts with a field tag ("sv", "bc", "isc"): such a segment can only sit where
+ * the string has a lower-case letter, and a modalias has a dozen of those - its start
+ * positions are taken from the set, leftmost first, instead of being searched word by word. */
 template <class Prog, class Str>
 MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, uint32_t hdr, const Str &s, uint32_t len,
-                           const uint32_t *sets)
+                           const uint32_t *sets, uint64_t lower = 0, bool have_lower = false)
 {
     const uint32_t minlen = MCX_HDR_MINLEN(hdr), flags = MCX_HDR_FLAGS(hdr), nseg = MCX_HDR_NSEG(hdr);
     if (flags & MCX_PF_NEVER)
@@ -365,6 +386,23 @@ MCX_HD bool mcx_prog_match(const Prog &p, uint32_t at, uint32_t hdr, const Str &
         const bool lit0 = (m0 & 0xFFu) == 0xFFu;
         const uint32_t rep = (v0 & 0xFFu) * 0x01010101u;
         bool found = false;
+        if (have_lower && lit0 && mcx_is_lower(v0 & 0xFFu)) {
+            /* lo <= hi <= 63 here: the segment fits the string */
+            uint64_t cand = lower & (~(uint64_t)0 << lo) & (~(uint64_t)0 >> (63u - hi));
+            while (cand != 0u && !found) {
+                const uint32_t q = (uint32_t)__builtin_ctzll(cand);
+                cand &= cand - 1u;
+                if ((s.word(q) ^ v0) & m0)
+                    continue;
+                if (mcx_seg_rest(p, g, 1u, s, q, sets)) {
+                    pos = q + g.nchars;
+                    found = true;
+                }
+            }
+            if (!found)
+                return false;
+            continue;
+        }
         for (uint32_t q = lo; q <= hi && !found; q += 4u) {
             const uint32_t w0 = s.word(q);
             uint32_t cand = 0x80808080u; /* bit 8d+7: start position q+d is worth a look */

@@ -109,6 +109,14 @@ int twin_fnmatch(const char *pattern, uint32_t pn, const char *string, uint32_t 
                 : 0;
     if ((match_like_device(slot, ext.data(), s, sn, sets) ? 1 : 0) != r)
         return -100; /* the two matchers disagree */
+    if (sn <= 64u) {
+        /* the tile kernel's way: start positions of tag segments from the set of lower-case positions */
+        const uint64_t lower = mcx_lower_set(s, sn);
+        const bool r2 = is_ext ? mcx_prog_match(HostProg{ext.data()}, slot[MCX_SLOT_DIR], slot[0], s, sn, sets, lower, true)
+                               : mcx_prog_match(HostProg{slot}, MCX_SLOT_BODY, slot[0], s, sn, sets, lower, true);
+        if ((r2 ? 1 : 0) != r)
+            return -101;
+    }
     return r;
 }
 
