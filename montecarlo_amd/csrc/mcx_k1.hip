@@ -903,7 +903,7 @@ k1_match_small(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                                 step adds up to K1T_THREADS of them */
 #endif
 #ifndef K1T_SCAP
-#define K1T_SCAP 960u        /* survivors waiting for a program run                  */
+#define K1T_SCAP 896u        /* survivors waiting for a program run                  */
 #endif
 #ifndef K1T_LOWER
 #define K1T_LOWER 1          /* 0: program runs without the strings' sets of lower-case positions (timing experiments) */
@@ -1580,7 +1580,7 @@ k1_match_tiles(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off
                uint32_t s_aligned, const k1_table_t T, uint32_t *__restrict__ first_idx,
                uint32_t *__restrict__ count, const k1_list_t L)
 {
-    static_assert(K1T_MIN_WAVES != 6 || sizeof(k1t_shared_t<0>) <= 26880u, "six blocks per CU: 26 880 bytes of LDS each");
+    static_assert(K1T_MIN_WAVES != 6 || sizeof(k1t_shared_t<MODE>) <= 26880u, "six blocks per CU: 26 880 bytes of LDS each");
     __shared__ k1t_shared_t<MODE> sh;
     const uint32_t t0 = blockIdx.x * spb;
     const uint32_t gbase = s_off[t0], gend = s_off[t0 + min(spb, N - t0)];

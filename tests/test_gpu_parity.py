@@ -615,6 +615,28 @@ def check_k2(ctx, oracle_mod, rowptr, col, flags, seeds):
     return out
 
 
+def test_k2_searches_of_changing_shape_on_one_graph(gpu_ctx, oracle_mod):
+    """a closure places its launches (the one-workgroup kernel, levels that claim without a look
+    first) by the frontier sizes of the LAST search in that direction on the same graph: searches
+    of very different shape one after the other, each twice, so that every choice is made on a
+    right guess and on a wrong one"""
+    V = 300000
+    rowptr, col = synth.dep_graph(11, V, 10)
+    flags = synth.dep_flags(11, rowptr, col)
+    gpu_ctx.dep_graph_load(rowptr, col)
+    expect = {}
+    for nseed in (1, 20000, 16, 16, 1, 400, 20000, 1, 16):
+        seeds, _ = synth.seed_bitmap(11 + nseed, flags, nseed)
+        for direction in (0, 1):
+            key = (nseed, direction)
+            if key not in expect:
+                expect[key] = oracle_mod.dep_closure(rowptr, col, flags, seeds, direction)
+            o_clo, o_edges, o_levels = expect[key]
+            clo, edges, levels = gpu_ctx.dep_closure(flags, seeds, direction)
+            assert np.array_equal(clo, o_clo), key
+            assert (edges, levels) == (o_edges, o_levels), key
+
+
 @pytest.mark.parametrize("seed,V,deg,nseed", [(3, 1000, 8, 3), (4, 50000, 10, 8), (5, 33, 3, 2), (6, 1, 1, 1)])
 def test_k2_vs_oracle(gpu_ctx, oracle_mod, seed, V, deg, nseed):
     rowptr, col = synth.dep_graph(seed, V, deg)
