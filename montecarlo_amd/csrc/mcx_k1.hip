@@ -1077,10 +1077,7 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
                 }
                 if (K1T_LOWER) {
                     const unsigned long long lw = __ballot(lane < len && mcx_is_lower(w & 0xFFu));
-                    if (lane == 0u) {
-                        lowm[slot][0] = (uint32_t)lw;
-                        lowm[slot][1] = (uint32_t)(lw >> 32);
-                    }
+                    lowm[slot][lane & 1u] = (lane & 1u) ? (uint32_t)(lw >> 32) : (uint32_t)lw; /* (all lanes: no branch) */
                 }
             }
             for (uint32_t q = lane + 64u; q + 4u <= len; q += 64u) {
@@ -2193,8 +2190,8 @@ static void k1_fill_table(const mcx_ctx *ctx, k1_table_t &T)
  * 42 / 34 at 12 288, 71 / 42 at 24 576).  Only the tile kernel uses the second index of the large groups, and
  * against a table with a very large group (every "of:" line of a table of 3 x 10^6 patterns
  * shares one prefix) that decides it whatever the batch: 1000 strings take 28 us with it
- * and 78 us without.  Test seam: MCX_BULK_MIN in the environment, read once when the table
- * is loaded, replaces the batch size (results do not depend on the kernel). */
+ * and 78 us without.  mcx_ctx_tune(MCX_TUNE_TILES_MIN) replaces the batch size for the tables
+ * loaded after it (results do not depend on the kernel). */
 static bool k1_use_tiles(const mcx_ctx *ctx, uint32_t N)
 {
     if (ctx->bulk_min_set)
