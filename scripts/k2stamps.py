@@ -31,7 +31,10 @@ for lv in range(20):
     if row[0] == 0:
         continue
     t = [(int(row[k]) - int(row[0])) / 100.0 if row[k] else None for k in range(11)]
-    print("level %2d: " % lv + "  ".join("%s %5.2f" % (names[k], t[k]) for k in range(1, 11) if t[k] is not None))
+    prev = out[lv - 1] if lv else None
+    gap = (int(row[0]) - int(max(prev[1:11]))) / 100.0 if prev is not None and prev[0] and row[0] > max(prev[1:11]) else None
+    print("level %2d: " % lv + ("(%5.2f after block 0 of the level before) " % gap if gap is not None else "")
+          + "  ".join("%s %5.2f" % (names[k], t[k]) for k in range(1, 11) if t[k] is not None))
 
 small = np.zeros((32, 8), dtype=np.uint64)
 assert ctx.lib.mcx_debug_k2s_stamps(ctypes.c_void_p(small.ctypes.data)) == 0
