@@ -34,7 +34,7 @@ static double now_us()
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int main()
+int main(int argc, char **argv)
 {
     hipStream_t s;
     CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -42,7 +42,7 @@ int main()
     uint32_t *d;
     CHECK(hipMalloc(&d, 4 * n));
     CHECK(hipMemset(d, 0, 4 * n));
-    const int chain = 200;
+    const int chain = argc > 1 ? atoi(argv[1]) : 200; /* launches per chain */
     for (int variant = 0; variant < 3; ++variant) {
         auto enqueue = [&]() {
             for (int i = 0; i < chain; ++i) {
@@ -57,7 +57,7 @@ int main()
         enqueue();
         CHECK(hipStreamSynchronize(s));
         double best = 1e30;
-        for (int r = 0; r < 5; ++r) {
+        for (int r = 0; r < 50; ++r) {
             const double t0 = now_us();
             enqueue();
             CHECK(hipStreamSynchronize(s));
@@ -74,7 +74,7 @@ int main()
         CHECK(hipGraphLaunch(ge, s));
         CHECK(hipStreamSynchronize(s));
         double bestg = 1e30;
-        for (int r = 0; r < 5; ++r) {
+        for (int r = 0; r < 50; ++r) {
             const double t0 = now_us();
             CHECK(hipGraphLaunch(ge, s));
             CHECK(hipStreamSynchronize(s));
@@ -82,9 +82,9 @@ int main()
             if (t < bestg)
                 bestg = t;
         }
-        printf("variant %d (%s): plain %.2f us per launch, graph %.2f us per launch\n", variant,
-               variant == 0 ? "one wave" : variant == 1 ? "256 blocks, 256 KB" : "4096 blocks, 4 MB", best / chain,
-               bestg / chain);
+        printf("variant %d (%s), chains of %d: plain %.2f us per launch (%.1f us a chain), graph %.2f us per launch (%.1f us a chain)\n",
+               variant, variant == 0 ? "one wave" : variant == 1 ? "256 blocks, 256 KB" : "4096 blocks, 4 MB", chain,
+               best / chain, best, bestg / chain, bestg);
         CHECK(hipGraphExecDestroy(ge));
         CHECK(hipGraphDestroy(g));
     }
