@@ -120,7 +120,8 @@ int mcx_ctx_create(int device_ordinal, void *stream, mcx_ctx **out)
         ctx->own_stream = true;
     }
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_pinned, 4 * MCX_PINNED_WORDS, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_pinned, 4 * MCX_PINNED_WORDS, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&ctx->d_pinned, ctx->h_pinned, 0) != hipSuccess) {
         mcx_ctx_destroy(ctx);
         return MCX_E_NO_DEVICE;
     }

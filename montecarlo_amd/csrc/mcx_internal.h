@@ -76,6 +76,7 @@ struct mcx_ctx {
     uint32_t n_hub[2] = {0, 0};    /* modules with a long adjacency list, per closure direction */
     uint32_t hub_cap = 0;
     uint32_t *h_pinned = nullptr;  /* MCX_PINNED_WORDS words of pinned host memory for small read-backs */
+    uint32_t *d_pinned = nullptr;  /* the same words as the device addresses them */
     uint32_t pinned_seq = 0;       /* last value a kernel was asked to leave in h_pinned[MCX_PINNED_SEQ_WORD] */
     std::vector<uint32_t> bfs_sizes[2]; /* per direction: the frontier sizes of the last closure's per-level
                                            launches (0xFFFFFFFF: a level with hubs) */
@@ -94,6 +95,7 @@ struct mcx_ctx {
     void *d_io = nullptr;
     size_t io_bytes = 0;
     void *h_io = nullptr;          /* pinned mirror of d_io for small host-buffer calls */
+    void *h_io_dev = nullptr;      /* h_io as the device addresses it */
     size_t h_io_bytes = 0;
 
     /* packed strings of the listed devices (inventory pipeline), grown on demand */

@@ -1617,8 +1617,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
     uint32_t *sizes = ctx->h_pinned;                                  /* 2 * K2B_BATCH words */
     unsigned long long *h_edges = (unsigned long long *)(ctx->h_pinned + 2 * K2B_BATCH);
     uint32_t *h_small = ctx->h_pinned + 2 * K2B_BATCH + 2;            /* levels, handed over */
-    uint32_t *d_sizes = nullptr; /* the same pinned memory as the device addresses it */
-    HIPCHK(ctx, hipHostGetDevicePointer((void **)&d_sizes, sizes, 0));
+    uint32_t *d_sizes = ctx->d_pinned; /* the same pinned memory as the device addresses it */
     k2b_report_t rep;
     rep.sizes = d_sizes;
     rep.edges = (unsigned long long *)(d_sizes + 2 * K2B_BATCH);
