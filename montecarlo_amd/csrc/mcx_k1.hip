@@ -1149,16 +1149,12 @@ k1_tiles_tile(const uint8_t *__restrict__ S, const uint32_t *__restrict__ s_off,
             const FlatProg fp{is_ext ? T.ext : sp};
             const uint32_t at = is_ext ? head.w : MCX_SLOT_BODY;
             bool ok;
-#if defined(K1T_EXP) && K1T_EXP == 1
-            ok = (hdr & 1u) != 0u || len != 0u;
-#else
             if (use_lds)
                 ok = mcx_prog_match(fp, at, hdr, LdsStr{(lds_words_t)str_w, str_at[slot]}, len, T.sets,
                                     (uint64_t)lowm[slot][0] | ((uint64_t)lowm[slot][1] << 32),
                                     K1T_LOWER != 0 && len <= 64u);
             else
                 ok = mcx_prog_match(fp, at, hdr, GlobalStr{S + gbase + str_at[slot], len, T.norm_dash}, len, T.sets);
-#endif
             if (ok)
                 hit(slot, kk, head.y, head.z);
         }

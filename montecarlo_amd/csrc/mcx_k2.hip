@@ -526,6 +526,9 @@ k2b_seed(const uint32_t *__restrict__ seed, const uint8_t *__restrict__ in_flags
 #define K2B_BUF 512u
 #ifndef K2B_LOOK_MAX
 #define K2B_LOOK_MAX 8192u /* frontier entries up to which a level towards the holders claims without a look (0: never) */
+#define K2B_LOOK_PER 128u  /* ... and no more than one entry per so many modules: claims on one cache line (512 modules)
+                              are served one after the other, and the smaller the graph the more of a level's claims
+                              share a line (6000 modules, 4 seeds: 79 us without the look, 61 with) */
 #endif
 #ifndef K2B_GMIN
 #define K2B_GMIN 16u
@@ -1700,7 +1703,7 @@ int mcx_dep_closure_dev(mcx_ctx *ctx, const void *d_in_flags, const void *d_seed
                                                                   queue[(level + 1u) & 1u], st, level, end_rep, seq_end,
                                                                   1u, base, dedup);
                 /* without the look where the last search's level was short (a wrong guess costs time only) */
-                if (dedup == 0u && known && last[g] <= K2B_LOOK_MAX)
+                if (dedup == 0u && known && last[g] <= K2B_LOOK_MAX && last[g] <= V / K2B_LOOK_PER)
                     k2b_expand<false><<<K2B_BLOCKS, K2_THREADS, 0, ctx->stream>>>(
                         rp, cl, queue[level & 1u], (uint32_t *)d_out_bitmap, queue[(level + 1u) & 1u], st, level,
                         sweep_waves, V, dedup);

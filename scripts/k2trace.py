@@ -1,4 +1,4 @@
-"""Diagnostic: a few closure calls of one configuration (env K2_SEEDS, K2_DIR), to be run under
+"""Diagnostic: a few closure calls of one configuration (env K2_V, K2_SEEDS, K2_DIR), to be run under
 rocprofv3 --kernel-trace; prints nothing but the call's results."""
 import os
 import sys
@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from montecarlo_amd import Context, synth  # noqa: E402
 
-V = 1000000
+V = int(os.environ.get("K2_V", 1000000))
 nseed, direction = int(os.environ.get("K2_SEEDS", 16)), int(os.environ.get("K2_DIR", 0))
 rowptr, col = synth.dep_graph(3, V, 10)
 flags = synth.dep_flags(3, rowptr, col)
