@@ -72,6 +72,44 @@ void mcx_free_graph(mcx_ctx *ctx)
     ctx->V = ctx->E = 0;
 }
 
+int mcx_pinned_io(mcx_ctx *ctx, uint8_t **host, uint8_t **dev)
+{
+    if (!ctx->h_io) {
+        if (hipHostMalloc(&ctx->h_io, MCX_ZERO_COPY_MAX, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+            ctx->h_io = nullptr;
+            ctx->err = "hipHostMalloc of the pinned staging area failed";
+            return MCX_E_NOMEM;
+        }
+        ctx->h_io_bytes = MCX_ZERO_COPY_MAX;
+        HIPCHK(ctx, hipHostGetDevicePointer(&ctx->h_io_dev, ctx->h_io, 0));
+    }
+    *host = (uint8_t *)ctx->h_io;
+    *dev = (uint8_t *)ctx->h_io_dev;
+    return MCX_OK;
+}
+
+/* one wave: an optional copy of a few words into pinned memory, then the sequence word, behind a
+ * system-scope fence */
+__global__ void mcx_done(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t copy_words,
+                         uint32_t *__restrict__ seq_word, uint32_t seq)
+{
+    for (uint32_t i = threadIdx.x; i < copy_words; i += blockDim.x)
+        dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int mcx_signal_and_wait(mcx_ctx *ctx, const uint32_t *src, uint32_t *dst, uint32_t copy_words)
+{
+    const uint32_t seq = mcx_next_seq(ctx);
+    mcx_done<<<1, copy_words > 64u ? 1024 : 64, 0, ctx->stream>>>(src, dst, copy_words,
+                                                                 ctx->d_pinned + MCX_PINNED_SEQ_WORD, seq);
+    HIPCHK(ctx, hipGetLastError());
+    return mcx_wait_seq(ctx, seq) ? MCX_E_HIP : MCX_OK;
+}
+
 extern "C" {
 
 const char *mcx_strerror(int rc)

@@ -221,6 +221,18 @@ static inline int mcx_wait_seq2(mcx_ctx *ctx, uint32_t early, uint32_t last)
     return 0;
 }
 
+/* Small host-buffer calls use no copies: their inputs are put into pinned host memory kept by the
+ * context (MCX_ZERO_COPY_MAX bytes, allocated at the first such call), the kernels read them there
+ * over the bus and write the results there.  mcx_pinned_io hands out that area as the host and as
+ * the device address it; mcx_signal_and_wait enqueues a one-wave launch that leaves a fresh
+ * sequence number in the report area behind everything the stream has done, and waits for it
+ * (mcx_wait_seq).  `copy_words` > 0: that launch first copies so many words from device memory
+ * `src` to `dst` (pinned, device address) - results that kernels reach with atomics stay in
+ * device memory until then.  (mcx_core.hip) */
+#define MCX_ZERO_COPY_MAX ((size_t)2048 << 10)
+int mcx_pinned_io(mcx_ctx *ctx, uint8_t **host, uint8_t **dev);
+int mcx_signal_and_wait(mcx_ctx *ctx, const uint32_t *src = nullptr, uint32_t *dst = nullptr, uint32_t copy_words = 0);
+
 static inline size_t up256(size_t x)
 {
     return (x + 255) & ~(size_t)255;

@@ -26,7 +26,6 @@
 #define K1_RING 2048u       /* survivors waiting for a program run, per block    */
 #define K1_UNIT 256u        /* patterns screened per wave step (4 per lane)       */
 #define K1_MAX_PATTERNS (1u << 26) /* survivor entries and group counts keep a pattern number in 26 bits */
-#define MCX_ZERO_COPY_MAX ((size_t)2048 << 10) /* host-buffer calls up to this size: the kernel works on pinned host memory */
 #define K1_QUARTER 64u   /* a group of at most this many patterns takes a quarter of a
                             screening step (16 lanes): four such groups share one */
 #define K1_LANEMAP 512u  /* small groups of one block that can share steps         */
@@ -2281,17 +2280,6 @@ int mcx_alias_match_dev(mcx_ctx *ctx, const void *d_S, const void *d_s_off, uint
                               (uint32_t *)d_first_idx, (uint32_t *)d_count);
 }
 
-/* Leaves the call's number in the sequence word of the pinned report area, behind everything the
- * stream has done before: the host spins on that word, which costs it a few microseconds where a
- * stream synchronisation costs about 25. */
-__global__ void k1_done(uint32_t *__restrict__ seq_word, uint32_t seq)
-{
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t N, uint32_t *first_idx,
                     uint32_t *count)
 {
@@ -2321,19 +2309,10 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
      * offsets are put into pinned host memory, the kernel reads them there (a few reads
      * over the bus per block) and writes the results there. */
     if (need <= MCX_ZERO_COPY_MAX) {
-        if (ctx->h_io_bytes < need) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipHostFree(ctx->h_io);
-            ctx->h_io = nullptr;
-            ctx->h_io_bytes = 0;
-            if (hipHostMalloc(&ctx->h_io, MCX_ZERO_COPY_MAX, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
-                ctx->err = "hipHostMalloc of the pinned staging area failed";
-                return MCX_E_NOMEM;
-            }
-            ctx->h_io_bytes = MCX_ZERO_COPY_MAX;
-            HIPCHK(ctx, hipHostGetDevicePointer(&ctx->h_io_dev, ctx->h_io, 0));
-        }
-        uint8_t *hb = (uint8_t *)ctx->h_io, *db = (uint8_t *)ctx->h_io_dev;
+        uint8_t *hb = nullptr, *db = nullptr;
+        const int rc_io = mcx_pinned_io(ctx, &hb, &db);
+        if (rc_io != MCX_OK)
+            return rc_io;
         if (sbytes)
             memcpy(hb, S, sbytes);
         memcpy(hb + o_off, s_off, 4 * ((size_t)N + 1));
@@ -2341,11 +2320,8 @@ int mcx_alias_match(mcx_ctx *ctx, const char *S, const uint32_t *s_off, uint32_t
                                      (uint32_t *)(db + o_count));
         if (rc0 != MCX_OK)
             return rc0;
-        const uint32_t seq = mcx_next_seq(ctx);
-        k1_done<<<1, 64, 0, ctx->stream>>>(ctx->d_pinned + MCX_PINNED_SEQ_WORD, seq);
-        HIPCHK(ctx, hipGetLastError());
-        if (mcx_wait_seq(ctx, seq))
-            return MCX_E_HIP;
+        if ((rc0 = mcx_signal_and_wait(ctx)) != MCX_OK)
+            return rc0;
         memcpy(first_idx, hb + o_first, 4 * (size_t)N);
         memcpy(count, hb + o_count, 4 * (size_t)N);
         return MCX_OK;

@@ -1504,6 +1504,9 @@ int mcx_dep_flags_noalloc_dev(mcx_ctx *ctx, const void *d_in_flags, void *d_out_
     return k2_enqueue_flags(ctx, d_in_flags, d_out_flags, d_refcnt, bm);
 }
 
+/* graphs up to this size take their host-buffer calls through pinned host memory */
+#define K2_ZERO_COPY_MODULES 65536u
+
 int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uint32_t *refcnt)
 {
     if (!ctx || !in_flags || !out_flags)
@@ -1515,8 +1518,24 @@ int mcx_dep_flags(mcx_ctx *ctx, const uint8_t *in_flags, uint8_t *out_flags, uin
         return MCX_OK;
     if (mcx_set_device(ctx))
         return MCX_E_HIP;
-    /* flags in, flags out, reference counts: three pieces of the context's staging area */
+    /* flags in, flags out, reference counts: three pieces of one staging area */
     const size_t piece = ((size_t)V + 255) & ~(size_t)255;
+    if (V <= K2_ZERO_COPY_MODULES) {
+        /* the module table of one host: in pinned host memory, read and written by the kernels over
+         * the bus (no copies, no stream synchronisation: mcx_internal.h) */
+        uint8_t *hb = nullptr, *db = nullptr;
+        int rc0 = mcx_pinned_io(ctx, &hb, &db);
+        if (rc0 != MCX_OK)
+            return rc0;
+        memcpy(hb, in_flags, V);
+        if ((rc0 = mcx_dep_flags_dev(ctx, db, db + piece, refcnt ? db + 2 * piece : nullptr)) != MCX_OK ||
+            (rc0 = mcx_signal_and_wait(ctx)) != MCX_OK)
+            return rc0;
+        memcpy(out_flags, hb + piece, V);
+        if (refcnt)
+            memcpy(refcnt, hb + 2 * piece, 4 * (size_t)V);
+        return MCX_OK;
+    }
     uint8_t *base = nullptr;
     int rc = mcx_io_reserve(ctx, 2 * piece + 4 * (size_t)V, &base);
     if (rc != MCX_OK)
@@ -1780,6 +1799,22 @@ int mcx_dep_closure(mcx_ctx *ctx, const uint8_t *in_flags, const uint32_t *seed_
     int rc = mcx_io_reserve(ctx, p_in + 2 * p_bm, &base);
     if (rc != MCX_OK)
         return rc;
+    if (V <= K2_ZERO_COPY_MODULES) {
+        /* one host's module table: flags and seeds are read in pinned host memory; the result stays in
+         * device memory while the search claims its bits and goes to pinned memory with the launch
+         * that tells the host */
+        uint8_t *hb = nullptr, *db = nullptr;
+        if ((rc = mcx_pinned_io(ctx, &hb, &db)) != MCX_OK)
+            return rc;
+        memcpy(hb, in_flags, V);
+        memcpy(hb + p_in, seed_bitmap, wb);
+        uint32_t *d_res = (uint32_t *)(base + p_in + p_bm);
+        if ((rc = mcx_dep_closure_dev(ctx, db, db + p_in, d_res, direction, edges_scanned, levels)) != MCX_OK ||
+            (rc = mcx_signal_and_wait(ctx, d_res, (uint32_t *)(db + p_in + p_bm), (uint32_t)(wb / 4))) != MCX_OK)
+            return rc;
+        memcpy(out_bitmap, hb + p_in + p_bm, wb);
+        return MCX_OK;
+    }
     uint8_t *d_in = base;
     uint32_t *d_seed = (uint32_t *)(base + p_in), *d_out = (uint32_t *)(base + p_in + p_bm);
     if (hipMemcpyAsync(d_in, in_flags, V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
