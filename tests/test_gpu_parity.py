@@ -645,6 +645,35 @@ def test_k2_vs_oracle(gpu_ctx, oracle_mod, seed, V, deg, nseed):
     check_k2(gpu_ctx, oracle_mod, rowptr, col, flags, seeds)
 
 
+@pytest.mark.parametrize("V", [1, 31, 65535, 65536, 65537, 70000])
+def test_k2_host_buffer_call_sizes(gpu_ctx, oracle_mod, V):
+    """The host-buffer calls of the dependency kernels work in pinned host memory on graphs of up to
+    65 536 modules and copy through a device staging area above: graphs on both sides of the switch,
+    calls of both kinds alternating with an alias match (which shares the pinned area), give the
+    oracle's flag bytes, reference counts, closures, edge counts and levels."""
+    rowptr, col = synth.dep_graph(21, V, 6)
+    flags = synth.dep_flags(21, rowptr, col, 150)
+    A, a_off, a_mod = synth.alias_table(13, 500)
+    S1, s1 = synth.modalias_strings(14, 500, 40)
+    gpu_ctx.alias_table_load(A, a_off, a_mod)
+    o1 = oracle_mod.alias_match(A, a_off, S1, s1)
+    gpu_ctx.dep_graph_load(rowptr, col)
+    o_out, o_ref = oracle_mod.dep_flags(rowptr, col, flags)
+    for nseed in (1, 50):
+        seeds, _ = synth.seed_bitmap(21 + nseed, flags, min(nseed, V))
+        for _ in range(2):
+            out, ref = gpu_ctx.dep_flags(flags)
+            assert np.array_equal(out, o_out) and np.array_equal(ref, o_ref)
+            out2, none = gpu_ctx.dep_flags(flags, want_refcnt=False)
+            assert np.array_equal(out2, o_out) and none is None
+            for direction in (0, 1):
+                clo, edges, levels = gpu_ctx.dep_closure(flags, seeds, direction)
+                o_clo, o_edges, o_levels = oracle_mod.dep_closure(rowptr, col, flags, seeds, direction)
+                assert np.array_equal(clo, o_clo) and (edges, levels) == (o_edges, o_levels)
+                f1, c1 = gpu_ctx.alias_match(S1, s1)
+                assert np.array_equal(f1, o1[0]) and np.array_equal(c1, o1[1])
+
+
 def test_k2_hand_graphs(gpu_ctx, oracle_mod):
     # chain, diamond, isolated vertices, nothing loaded, everything seeded
     rowptr = np.array([0, 0, 1, 2, 3], dtype=np.uint32)
